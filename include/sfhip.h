@@ -1,0 +1,429 @@
+/*
+ * sfhip.h -- C ABI of libsfhip.so, the MI355X (gfx950) implementation of
+ * sailfish's cbdiso_2d / cbdgam_2d finite-volume update.
+ *
+ * Drop-in boundary.  The reference loads a shared object with ctypes.CDLL and
+ * calls `void <kernel>(int ni, int nj, <args in source order>)`
+ * (sailfish/kernel/library.py:99-117, 252-264).  The entry points below that
+ * carry a reference name have EXACTLY the reference's argument list (types,
+ * order, meaning), so `lib.<kernel>[shape](*args)` in sailfish's Patch classes
+ * works unchanged; the only differences are
+ *   - `double *` arguments are DEVICE pointers (HBM of the current device);
+ *   - the launch is asynchronous on the calling thread's current stream
+ *     (sfhip_set_stream), like the reference's cupy `gpu` mode;
+ *   - functions return int (0 = ok) instead of void; a caller that ignores the
+ *     value, as a `void` binding does, is still ABI-correct.  The reference has
+ *     no error channel at all; ours is sfhip_last_error().
+ *
+ * This header is also the single source of truth for the Python loader:
+ * sailfish_amd/kernel/parse_api.py reads the declarations (one argument per
+ * line, optional `// :: <constraint>` comments -- the convention of
+ * sailfish/kernel/parse_api.py:29-84 and doc/source/kernels.rst:138-157) and
+ * derives ctypes signatures and the kernel rank (number of leading ints).
+ *
+ * Array layout everywhere: C-contiguous (ni + 4, nj + 4, NCONS) fp64, two guard
+ * zones per side (cbdiso_2d.c:443-445).  Kernels write interior zones only.
+ */
+#ifndef SFHIP_H
+#define SFHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFHIP_API
+
+/* ---------------------------------------------------------------- runtime --
+ * No counterpart in the reference's C kernels; they replace what cupy's
+ * current-device / current-stream state does for its `gpu` mode
+ * (sailfish/kernel/system.py:122-135, library.py:118-135).
+ */
+int sfhip_set_device(int device);
+int sfhip_device_count(void);
+int sfhip_set_stream(void *stream); /* hipStream_t; thread-local; NULL = default stream */
+int sfhip_synchronize(void);        /* hipStreamSynchronize on the current stream */
+const char *sfhip_last_error(void); /* thread-local message of the last failing call */
+int sfhip_selftest_lane_shift(const double *in64, double *out_below64, double *out_above64);
+
+/* Replaces `self.wavespeeds.max()` (cbdiso_2d.py:174, cbdgam_2d.py:152): max of
+ * n non-negative doubles into *out (device scalar). */
+SFHIP_API int sfhip_max_nonneg(
+    int n,
+    double *x, // :: $.numel() >= n
+    double *out) // :: $.numel() >= 1
+;
+
+/* ---------------------------------------------------------------- cbdiso_2d */
+
+/* Replaces cbdiso_2d_advance_rk, sailfish/solvers/cbdiso_2d.c:385-604
+ * (caller: Patch.advance_rk, cbdiso_2d.py:186-240). */
+SFHIP_API int cbdiso_2d_advance_rk(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double *conserved_rk, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *primitive_rd, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *primitive_wr, // :: $.shape == (ni + 4, nj + 4, 3)
+    double buffer_surface_density,
+    double buffer_central_mass,
+    double buffer_driving_rate,
+    double buffer_outer_radius,
+    double buffer_onset_width,
+    int buffer_is_enabled,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double cs2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double nu, // kinematic viscosity coefficient
+    double a, // RK parameter
+    double dt, // timestep
+    double velocity_ceiling,
+    double density_floor)
+;
+
+/* Replaces cbdiso_2d_primitive_to_conserved, cbdiso_2d.c:606-624
+ * (caller: Patch.recompute_conserved, cbdiso_2d.py:176-184). */
+SFHIP_API int cbdiso_2d_primitive_to_conserved(
+    int ni,
+    int nj,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *conserved) // :: $.shape == (ni + 4, nj + 4, 3)
+;
+
+/* Replaces cbdiso_2d_point_mass_source_term, cbdiso_2d.c:626-664
+ * (caller: Patch.point_mass_source_term, cbdiso_2d.py:105-137). */
+SFHIP_API int cbdiso_2d_point_mass_source_term(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double x1, // particle
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *cons_rate) // :: $.shape == (ni + 4, nj + 4, 3)
+;
+
+/* Replaces cbdiso_2d_wavespeed, cbdiso_2d.c:666-722
+ * (caller: Patch.maximum_wavespeed, cbdiso_2d.py:139-174).  Bit-exact. */
+SFHIP_API int cbdiso_2d_wavespeed(
+    int ni, // mesh
+    int nj,
+    double patch_xl,
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double soundspeed2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *wavespeed) // :: $.shape == (ni + 4, nj + 4)
+;
+
+/* Fused stage.  cbdiso_2d_advance_rk plus the passes the reference runs around
+ * it: Solver.set_bc outflow copies (cbdiso_2d.py:553-586) become index clamps,
+ * Patch.recompute_conserved (cbdiso_2d.py:176-184) becomes un_mode 2, and
+ * Patch.maximum_wavespeed of the OUTPUT state (cbdiso_2d.py:139-174) becomes
+ * want_wavespeed (0 off, 1 accumulate into *wavespeed_max, 2 zero it first).
+ * Only zone rows [i_begin, i_end) are updated (interior / boundary split while
+ * halos are in flight).  The w* arguments are the point masses at the time the
+ * output state belongs to. */
+SFHIP_API int sfhip_cbdiso_2d_stage(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double *un_source, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *primitive_rd, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *primitive_wr, // :: $.shape == (ni + 4, nj + 4, 3)
+    double buffer_surface_density,
+    double buffer_central_mass,
+    double buffer_driving_rate,
+    double buffer_outer_radius,
+    double buffer_onset_width,
+    int buffer_is_enabled,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double cs2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double nu, // kinematic viscosity coefficient
+    double a, // RK parameter
+    double dt, // timestep
+    double velocity_ceiling,
+    double density_floor,
+    int un_mode, // :: $ in [0, 1, 2]
+    int clamp_ilo,
+    int clamp_ihi,
+    int i_begin, // :: 0 <= $ <= ni
+    int i_end, // :: i_begin <= $ <= ni
+    int want_wavespeed, // :: $ in [0, 1, 2]
+    double wx1, // point masses at the output time
+    double wy1,
+    double wmass1,
+    double wsoftening_length1,
+    double wx2,
+    double wy2,
+    double wmass2,
+    double wsoftening_length2,
+    double *wavespeed_max) // :: $.numel() >= 1
+;
+
+/* Wavespeed kernel + max in one pass (no per-zone array): replaces the pair
+ * cbdiso_2d_wavespeed + xp.max(), cbdiso_2d.py:139-174.  Bit-exact. */
+SFHIP_API int sfhip_cbdiso_2d_max_wavespeed(
+    int ni,
+    int nj,
+    double patch_xl,
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double soundspeed2,
+    double mach_squared,
+    int eos_type,
+    double x1,
+    double y1,
+    double mass1,
+    double softening_length1,
+    double x2,
+    double y2,
+    double mass2,
+    double softening_length2,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *wavespeed_max) // :: $.numel() >= 1
+;
+
+/* ---------------------------------------------------------------- cbdgam_2d */
+
+/* Replaces cbdgam_2d_advance_rk, sailfish/solvers/cbdgam_2d.c:439-683
+ * (caller: Patch.advance_rk, cbdgam_2d.py:162-215). */
+SFHIP_API int cbdgam_2d_advance_rk(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double *conserved_rk, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *primitive_rd, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *primitive_wr, // :: $.shape == (ni + 4, nj + 4, 4)
+    double gamma_law_index,
+    double buffer_surface_density,
+    double buffer_surface_pressure,
+    double buffer_central_mass,
+    double buffer_driving_rate,
+    double buffer_outer_radius,
+    double buffer_onset_width,
+    int buffer_is_enabled,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double alpha, // other
+    double a,
+    double dt,
+    double velocity_ceiling,
+    double cooling_coefficient,
+    double mach_ceiling,
+    double density_floor,
+    double pressure_floor,
+    int constant_softening)
+;
+
+/* Replaces cbdgam_2d_wavespeed, cbdgam_2d.c:685-708 (caller cbdgam_2d.py:145-152). */
+SFHIP_API int cbdgam_2d_wavespeed(
+    int ni,
+    int nj,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *wavespeed, // :: $.shape == (ni + 4, nj + 4)
+    double gamma_law_index)
+;
+
+/* Replaces cbdgam_2d_primitive_to_conserved, cbdgam_2d.c:710-729 (caller cbdgam_2d.py:154-160). */
+SFHIP_API int cbdgam_2d_primitive_to_conserved(
+    int ni,
+    int nj,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *conserved, // :: $.shape == (ni + 4, nj + 4, 4)
+    double gamma_law_index)
+;
+
+/* Replaces cbdgam_2d_point_mass_source_term, cbdgam_2d.c:731-784 (caller cbdgam_2d.py:104-143). */
+SFHIP_API int cbdgam_2d_point_mass_source_term(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    int which_mass, // :: $ in [1, 2]
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *cons_rate, // :: $.shape == (ni + 4, nj + 4, 4)
+    int constant_softening,
+    double gamma_law_index)
+;
+
+/* Fused stage for cbdgam_2d; flags as for sfhip_cbdiso_2d_stage.  The
+ * gamma-law wavespeed needs no point masses (cbdgam_2d.c:685-708). */
+SFHIP_API int sfhip_cbdgam_2d_stage(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double *un_source, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *primitive_rd, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *primitive_wr, // :: $.shape == (ni + 4, nj + 4, 4)
+    double gamma_law_index,
+    double buffer_surface_density,
+    double buffer_surface_pressure,
+    double buffer_central_mass,
+    double buffer_driving_rate,
+    double buffer_outer_radius,
+    double buffer_onset_width,
+    int buffer_is_enabled,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double alpha, // other
+    double a,
+    double dt,
+    double velocity_ceiling,
+    double cooling_coefficient,
+    double mach_ceiling,
+    double density_floor,
+    double pressure_floor,
+    int constant_softening,
+    int un_mode, // :: $ in [0, 1, 2]
+    int clamp_ilo,
+    int clamp_ihi,
+    int i_begin, // :: 0 <= $ <= ni
+    int i_end, // :: i_begin <= $ <= ni
+    int want_wavespeed, // :: $ in [0, 1, 2]
+    double *wavespeed_max) // :: $.numel() >= 1
+;
+
+SFHIP_API int sfhip_cbdgam_2d_max_wavespeed(
+    int ni,
+    int nj,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 4)
+    double gamma_law_index,
+    double *wavespeed_max) // :: $.numel() >= 1
+;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFHIP_H */

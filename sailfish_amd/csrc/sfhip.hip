@@ -1,0 +1,476 @@
+// sfhip.hip -- C-ABI of libsfhip.so: hand-written gfx950 kernels for sailfish's
+// cbdiso_2d / cbdgam_2d finite-volume update.  Declarations, with the reference
+// interface each entry point replaces, are in include/sfhip.h.
+//
+// Conventions
+//   * every pointer is a DEVICE pointer on the current device;
+//   * launches go to the calling thread's current stream (sfhip_set_stream),
+//     nothing here synchronises or allocates;
+//   * entry points return 0 on success, a hipError_t value (or -1 for argument
+//     errors) otherwise; sfhip_last_error() describes the last failure.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "sf_gam.hpp"
+#include "sf_iso.hpp"
+#include "sfhip.h"
+
+namespace {
+
+thread_local hipStream_t t_stream = nullptr;
+thread_local char t_error[512] = "";
+
+int fail(int code, const char *what)
+{
+    snprintf(t_error, sizeof(t_error), "%s", what);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(t_error, sizeof(t_error), "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+int env_int(const char *name, int fallback)
+{
+    const char *s = getenv(name);
+    return s && *s ? atoi(s) : fallback;
+}
+
+// Split `nrows` rows into chunks so that the launch has several waves per SIMD
+// on all 256 CUs (1024 SIMDs), without making chunks so short that the 4-row
+// pipeline warm-up dominates.
+void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
+{
+    int rpc = env_int("SFHIP_ROWS_PER_CHUNK", 0);
+    if (rpc <= 0) {
+        const int target_waves = env_int("SFHIP_TARGET_WAVES", 8192);
+        int nc = (target_waves + nstrips - 1) / nstrips;
+        int max_nc = (nrows + 31) / 32; // at least 32 rows per chunk
+        if (nc > max_nc) nc = max_nc;
+        if (nc < 1) nc = 1;
+        rpc = (nrows + nc - 1) / nc;
+    }
+    if (rpc < 1) rpc = 1;
+    *rows_per_chunk = rpc;
+    *nchunks = (nrows + rpc - 1) / rpc;
+}
+
+sf::Mass make_mass(double x, double y, double vx, double vy, double mass, double rsoft, double rate, double rsink, int model)
+{
+    sf::Mass m;
+    m.x = x; m.y = y; m.vx = vx; m.vy = vy; m.mass = mass; m.rsoft = rsoft;
+    m.sink_rate = rate; m.sink_radius = rsink; m.sink_model = model; m.pad_ = 0;
+    return m;
+}
+
+int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, double *pwr, double *wmax)
+{
+    if (P.ni < 1 || P.nj < 1) return fail(-1, "cbdiso_2d stage: ni, nj must be >= 1");
+    if (!prd || !pwr) return fail(-1, "cbdiso_2d stage: null primitive array");
+    if (prd == pwr) return fail(-1, "cbdiso_2d stage: primitive_rd and primitive_wr must not alias");
+    if (P.un_mode && !unsrc) return fail(-1, "cbdiso_2d stage: a != 0 needs the u^n source array");
+    if (P.want_wavespeed && !wmax) return fail(-1, "cbdiso_2d stage: want_wavespeed needs wmax");
+    if (P.i_begin < 0 || P.i_end > P.ni || P.i_begin > P.i_end) return fail(-1, "cbdiso_2d stage: bad row range");
+    if (P.want_wavespeed == 2) {
+        hipError_t e = hipMemsetAsync(wmax, 0, sizeof(double), t_stream);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    const int nrows = P.i_end - P.i_begin;
+    if (nrows == 0) return 0;
+    const int nstrips = (P.nj + sf::STRIP - 1) / sf::STRIP;
+    int nchunks;
+    plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
+    const long waves = (long)nstrips * nchunks;
+    const int wpb = 4;
+    dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(sf::iso_stage_kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
+    return check_launch("cbdiso_2d stage launch");
+}
+
+int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, double *pwr, double *wmax)
+{
+    if (P.ni < 1 || P.nj < 1) return fail(-1, "cbdgam_2d stage: ni, nj must be >= 1");
+    if (!prd || !pwr) return fail(-1, "cbdgam_2d stage: null primitive array");
+    if (prd == pwr) return fail(-1, "cbdgam_2d stage: primitive_rd and primitive_wr must not alias");
+    if (P.un_mode && !unsrc) return fail(-1, "cbdgam_2d stage: a != 0 needs the u^n source array");
+    if (P.want_wavespeed && !wmax) return fail(-1, "cbdgam_2d stage: want_wavespeed needs wmax");
+    if (P.i_begin < 0 || P.i_end > P.ni || P.i_begin > P.i_end) return fail(-1, "cbdgam_2d stage: bad row range");
+    if (P.want_wavespeed == 2) {
+        hipError_t e = hipMemsetAsync(wmax, 0, sizeof(double), t_stream);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    const int nrows = P.i_end - P.i_begin;
+    if (nrows == 0) return 0;
+    const int nstrips = (P.nj + sf::STRIP - 1) / sf::STRIP;
+    int nchunks;
+    plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
+    const long waves = (long)nstrips * nchunks;
+    const int wpb = 4;
+    dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(sf::gam_stage_kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
+    return check_launch("cbdgam_2d stage launch");
+}
+
+void fill_iso(sf::IsoParams &P, int ni, int nj, double pxl, double pxr, double pyl, double pyr,
+              double bsd, double bmc, double brate, double brout, double bw, int bon,
+              const sf::Mass &m1, const sf::Mass &m2, double cs2, double mach2, int eos,
+              double nu, double a, double dt, double vmax, double dfloor)
+{
+    memset(&P, 0, sizeof(P));
+    P.ni = ni; P.nj = nj;
+    P.xl = pxl; P.yl = pyl;
+    P.dx = (pxr - pxl) / ni; // cbdiso_2d.c:440-441
+    P.dy = (pyr - pyl) / nj;
+    P.m[0] = m1; P.m[1] = m2;
+    P.buf_sd = bsd; P.buf_mc = bmc; P.buf_rate = brate; P.buf_rout = brout;
+    P.buf_ron = brout - bw;                               // cbdiso_2d.c:229
+    P.buf_omega = sqrt(bmc * pow(P.buf_ron, -3.0));       // cbdiso_2d.c:237 (host libm, as the reference)
+    P.buf_on = bon;
+    P.eos = eos; P.cs2 = cs2; P.mach2 = mach2;
+    P.nu = nu; P.a = a; P.dt = dt; P.vmax = vmax; P.dfloor = dfloor;
+    P.clamp_ilo = P.clamp_ihi = P.clamp_j = 0;
+    P.un_mode = a != 0.0 ? 1 : 0;
+    P.i_begin = 0; P.i_end = ni;
+    P.want_wavespeed = 0;
+    P.mw[0] = m1; P.mw[1] = m2;
+}
+
+void fill_gam(sf::GamParams &P, int ni, int nj, double pxl, double pxr, double pyl, double pyr, double gamma,
+              double bsd, double bsp, double bmc, double brate, double brout, double bw, int bon,
+              const sf::Mass &m1, const sf::Mass &m2, double alpha, double a, double dt, double vmax,
+              double cooling, double mach_ceiling, double dfloor, double pfloor, int constant_softening)
+{
+    memset(&P, 0, sizeof(P));
+    P.ni = ni; P.nj = nj;
+    P.xl = pxl; P.yl = pyl;
+    P.dx = (pxr - pxl) / ni; // cbdgam_2d.c:498-499
+    P.dy = (pyr - pyl) / nj;
+    P.m[0] = m1; P.m[1] = m2;
+    P.gamma = gamma;
+    P.buf_sd = bsd; P.buf_sp = bsp; P.buf_mc = bmc; P.buf_rate = brate; P.buf_rout = brout;
+    P.buf_ron = brout - bw;                               // cbdgam_2d.c:255
+    P.buf_omega = sqrt(bmc * pow(P.buf_ron, -3.0));       // cbdgam_2d.c:266
+    P.buf_on = bon;
+    P.constant_softening = constant_softening;
+    P.alpha = alpha; P.a = a; P.dt = dt; P.vmax = vmax; P.cooling = cooling;
+    P.mach_ceiling_m2 = pow(mach_ceiling, -2.0);          // cbdgam_2d.c:314
+    P.dfloor = dfloor; P.pfloor = pfloor;
+    P.un_mode = a != 0.0 ? 1 : 0;
+    P.i_begin = 0; P.i_end = ni;
+}
+
+__global__ void max_nonneg_kernel(const double *__restrict__ x, long n, double *__restrict__ out)
+{
+    double a = 0.0;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        double v = x[k];
+        a = v > a ? v : a;
+    }
+    a = sf::wave_max_nonneg(a);
+    if ((threadIdx.x & 63) == 0) sf::atomic_max_nonneg(out, a);
+}
+
+// lane-shift self test: out_below[t] = value from lane t-1, out_above[t] = value from lane t+1
+__global__ void lane_shift_kernel(const double *in, double *out_below, double *out_above)
+{
+    int t = threadIdx.x;
+    double x = in[t];
+    out_below[t] = sf::from_lane_below(x);
+    out_above[t] = sf::from_lane_above(x);
+}
+
+} // namespace
+
+extern "C" {
+
+int sfhip_set_device(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+int sfhip_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int sfhip_set_stream(void *stream)
+{
+    t_stream = (hipStream_t)stream;
+    return 0;
+}
+
+int sfhip_synchronize(void)
+{
+    hipError_t e = hipStreamSynchronize(t_stream);
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+const char *sfhip_last_error(void) { return t_error; }
+
+int sfhip_selftest_lane_shift(const double *in64, double *out_below64, double *out_above64)
+{
+    hipLaunchKernelGGL(lane_shift_kernel, dim3(1), dim3(64), 0, t_stream, in64, out_below64, out_above64);
+    return check_launch("lane_shift_kernel");
+}
+
+// max over an array of non-negative doubles into *out (device); zeroes *out first
+int sfhip_max_nonneg(int n, double *x, double *out)
+{
+    if (!x || !out || n < 0) return fail(-1, "sfhip_max_nonneg: bad arguments");
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), t_stream);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    if (n == 0) return 0;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(max_nonneg_kernel, dim3((unsigned)blocks), dim3(256), 0, t_stream, x, n, out);
+    return check_launch("max_nonneg_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// cbdiso_2d -- reference-named entry points
+// ---------------------------------------------------------------------------
+int cbdiso_2d_advance_rk(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *conserved_rk, double *primitive_rd, double *primitive_wr,
+    double buffer_surface_density, double buffer_central_mass, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double cs2, double mach_squared, int eos_type, double nu, double a, double dt,
+    double velocity_ceiling, double density_floor)
+{
+    sf::IsoParams P;
+    fill_iso(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+             buffer_surface_density, buffer_central_mass, buffer_driving_rate, buffer_outer_radius,
+             buffer_onset_width, buffer_is_enabled,
+             make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+             make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+             cs2, mach_squared, eos_type, nu, a, dt, velocity_ceiling, density_floor);
+    return launch_iso_stage(P, primitive_rd, conserved_rk, primitive_wr, nullptr);
+}
+
+// Fused stage: cbdiso_2d_advance_rk plus the passes the reference runs around it.
+int sfhip_cbdiso_2d_stage(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *un_source, double *primitive_rd, double *primitive_wr,
+    double buffer_surface_density, double buffer_central_mass, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double cs2, double mach_squared, int eos_type, double nu, double a, double dt,
+    double velocity_ceiling, double density_floor,
+    int un_mode, int clamp_ilo, int clamp_ihi, int i_begin, int i_end, int want_wavespeed,
+    double wx1, double wy1, double wmass1, double wsoftening_length1,
+    double wx2, double wy2, double wmass2, double wsoftening_length2,
+    double *wavespeed_max)
+{
+    sf::IsoParams P;
+    fill_iso(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+             buffer_surface_density, buffer_central_mass, buffer_driving_rate, buffer_outer_radius,
+             buffer_onset_width, buffer_is_enabled,
+             make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+             make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+             cs2, mach_squared, eos_type, nu, a, dt, velocity_ceiling, density_floor);
+    P.un_mode = a != 0.0 ? un_mode : 0;
+    P.clamp_ilo = clamp_ilo; P.clamp_ihi = clamp_ihi; P.clamp_j = 1;
+    P.i_begin = i_begin; P.i_end = i_end;
+    P.want_wavespeed = want_wavespeed;
+    P.mw[0] = make_mass(wx1, wy1, 0, 0, wmass1, wsoftening_length1, 0, 0, 0);
+    P.mw[1] = make_mass(wx2, wy2, 0, 0, wmass2, wsoftening_length2, 0, 0, 0);
+    return launch_iso_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
+}
+
+int cbdiso_2d_primitive_to_conserved(int ni, int nj, double *primitive, double *conserved)
+{
+    if (ni < 1 || nj < 1 || !primitive || !conserved) return fail(-1, "cbdiso_2d_primitive_to_conserved: bad arguments");
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::iso_p2c_kernel, grid, block, 0, t_stream, ni, nj, primitive, conserved);
+    return check_launch("cbdiso_2d_primitive_to_conserved");
+}
+
+static int iso_wavespeed_impl(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double soundspeed2, double mach_squared, int eos_type, const sf::Mass &m1, const sf::Mass &m2,
+    double *primitive, double *wavespeed, double *wmax)
+{
+    if (ni < 1 || nj < 1 || !primitive) return fail(-1, "cbdiso_2d_wavespeed: bad arguments");
+    sf::IsoParams P;
+    fill_iso(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, 0, 0, 0, 0, 0, 0, m1, m2,
+             soundspeed2, mach_squared, eos_type, 0, 0, 0, 0, 0);
+    if (wmax) {
+        hipError_t e = hipMemsetAsync(wmax, 0, sizeof(double), t_stream);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    int gy = ni < 512 ? ni : 512;
+    dim3 block(256), grid((nj + 255) / 256, gy);
+    hipLaunchKernelGGL(sf::iso_wavespeed_kernel, grid, block, 0, t_stream, P, primitive, wavespeed, wmax);
+    return check_launch("cbdiso_2d_wavespeed");
+}
+
+int cbdiso_2d_wavespeed(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double soundspeed2, double mach_squared, int eos_type,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double *primitive, double *wavespeed)
+{
+    if (!wavespeed) return fail(-1, "cbdiso_2d_wavespeed: null output");
+    return iso_wavespeed_impl(ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, soundspeed2, mach_squared, eos_type,
+        make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+        make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+        primitive, wavespeed, nullptr);
+}
+
+// wavespeed + max in one pass, no per-zone array (replaces kernel + xp.max(), cbdiso_2d.py:139-174)
+int sfhip_cbdiso_2d_max_wavespeed(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double soundspeed2, double mach_squared, int eos_type,
+    double x1, double y1, double mass1, double softening_length1,
+    double x2, double y2, double mass2, double softening_length2,
+    double *primitive, double *wavespeed_max)
+{
+    if (!wavespeed_max) return fail(-1, "sfhip_cbdiso_2d_max_wavespeed: null output");
+    return iso_wavespeed_impl(ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, soundspeed2, mach_squared, eos_type,
+        make_mass(x1, y1, 0, 0, mass1, softening_length1, 0, 0, 0),
+        make_mass(x2, y2, 0, 0, mass2, softening_length2, 0, 0, 0),
+        primitive, nullptr, wavespeed_max);
+}
+
+int cbdiso_2d_point_mass_source_term(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double *primitive, double *cons_rate)
+{
+    if (ni < 1 || nj < 1 || !primitive || !cons_rate) return fail(-1, "cbdiso_2d_point_mass_source_term: bad arguments");
+    sf::IsoParams P;
+    sf::Mass m1 = make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1);
+    fill_iso(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, 0, 0, 0, 0, 0, 0, m1, m1, 0, 0, 0, 0, 0, 0, 0, 0);
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::iso_mass_rate_kernel, grid, block, 0, t_stream, P, primitive, cons_rate);
+    return check_launch("cbdiso_2d_point_mass_source_term");
+}
+
+// ---------------------------------------------------------------------------
+// cbdgam_2d -- reference-named entry points
+// ---------------------------------------------------------------------------
+int cbdgam_2d_advance_rk(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *conserved_rk, double *primitive_rd, double *primitive_wr,
+    double gamma_law_index,
+    double buffer_surface_density, double buffer_surface_pressure, double buffer_central_mass,
+    double buffer_driving_rate, double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double alpha, double a, double dt, double velocity_ceiling, double cooling_coefficient,
+    double mach_ceiling, double density_floor, double pressure_floor, int constant_softening)
+{
+    sf::GamParams P;
+    fill_gam(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, gamma_law_index,
+             buffer_surface_density, buffer_surface_pressure, buffer_central_mass, buffer_driving_rate,
+             buffer_outer_radius, buffer_onset_width, buffer_is_enabled,
+             make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+             make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+             alpha, a, dt, velocity_ceiling, cooling_coefficient, mach_ceiling, density_floor, pressure_floor,
+             constant_softening);
+    return launch_gam_stage(P, primitive_rd, conserved_rk, primitive_wr, nullptr);
+}
+
+int sfhip_cbdgam_2d_stage(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *un_source, double *primitive_rd, double *primitive_wr,
+    double gamma_law_index,
+    double buffer_surface_density, double buffer_surface_pressure, double buffer_central_mass,
+    double buffer_driving_rate, double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double alpha, double a, double dt, double velocity_ceiling, double cooling_coefficient,
+    double mach_ceiling, double density_floor, double pressure_floor, int constant_softening,
+    int un_mode, int clamp_ilo, int clamp_ihi, int i_begin, int i_end, int want_wavespeed,
+    double *wavespeed_max)
+{
+    sf::GamParams P;
+    fill_gam(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, gamma_law_index,
+             buffer_surface_density, buffer_surface_pressure, buffer_central_mass, buffer_driving_rate,
+             buffer_outer_radius, buffer_onset_width, buffer_is_enabled,
+             make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+             make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+             alpha, a, dt, velocity_ceiling, cooling_coefficient, mach_ceiling, density_floor, pressure_floor,
+             constant_softening);
+    P.un_mode = a != 0.0 ? un_mode : 0;
+    P.clamp_ilo = clamp_ilo; P.clamp_ihi = clamp_ihi; P.clamp_j = 1;
+    P.i_begin = i_begin; P.i_end = i_end;
+    P.want_wavespeed = want_wavespeed;
+    return launch_gam_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
+}
+
+int cbdgam_2d_wavespeed(int ni, int nj, double *primitive, double *wavespeed, double gamma_law_index)
+{
+    if (ni < 1 || nj < 1 || !primitive || !wavespeed) return fail(-1, "cbdgam_2d_wavespeed: bad arguments");
+    int gy = ni < 512 ? ni : 512;
+    dim3 block(256), grid((nj + 255) / 256, gy);
+    hipLaunchKernelGGL(sf::gam_wavespeed_kernel, grid, block, 0, t_stream, ni, nj, gamma_law_index, primitive, wavespeed, (double *)nullptr);
+    return check_launch("cbdgam_2d_wavespeed");
+}
+
+int sfhip_cbdgam_2d_max_wavespeed(int ni, int nj, double *primitive, double gamma_law_index, double *wavespeed_max)
+{
+    if (ni < 1 || nj < 1 || !primitive || !wavespeed_max) return fail(-1, "sfhip_cbdgam_2d_max_wavespeed: bad arguments");
+    hipError_t e = hipMemsetAsync(wavespeed_max, 0, sizeof(double), t_stream);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    int gy = ni < 512 ? ni : 512;
+    dim3 block(256), grid((nj + 255) / 256, gy);
+    hipLaunchKernelGGL(sf::gam_wavespeed_kernel, grid, block, 0, t_stream, ni, nj, gamma_law_index, primitive, (double *)nullptr, wavespeed_max);
+    return check_launch("sfhip_cbdgam_2d_max_wavespeed");
+}
+
+int cbdgam_2d_primitive_to_conserved(int ni, int nj, double *primitive, double *conserved, double gamma_law_index)
+{
+    if (ni < 1 || nj < 1 || !primitive || !conserved) return fail(-1, "cbdgam_2d_primitive_to_conserved: bad arguments");
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::gam_p2c_kernel, grid, block, 0, t_stream, ni, nj, gamma_law_index, primitive, conserved);
+    return check_launch("cbdgam_2d_primitive_to_conserved");
+}
+
+int cbdgam_2d_point_mass_source_term(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    int which_mass, double *primitive, double *cons_rate, int constant_softening, double gamma_law_index)
+{
+    if (ni < 1 || nj < 1 || !primitive || !cons_rate) return fail(-1, "cbdgam_2d_point_mass_source_term: bad arguments");
+    if (which_mass != 1 && which_mass != 2) return fail(-1, "cbdgam_2d_point_mass_source_term: which_mass must be 1 or 2");
+    sf::GamParams P;
+    fill_gam(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, gamma_law_index, 0, 0, 0, 0, 0, 0, 0,
+             make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+             make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+             0, 0, 0, 0, 0, 1.0, 0, 0, constant_softening);
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::gam_mass_rate_kernel, grid, block, 0, t_stream, P, which_mass - 1, primitive, cons_rate);
+    return check_launch("cbdgam_2d_point_mass_source_term");
+}
+
+} // extern "C"

@@ -1,0 +1,270 @@
+"""
+The two setups that feed the hot path.
+
+``CircumbinaryDisk`` is the benchmark problem (reference:
+``sailfish/setups/circumbinary_disk.py:17-215``): it defines the synthetic input
+of every BASELINE.json config (initial data per point, physics dict, point-mass
+callback).  ``CylindricalExplosion`` (``sailfish/setups/simple2d.py:40-114``) is
+the minimal-physics second parity input.  The reference's ``SetupBase``
+machinery (model-parameter parsing, registry, CLI help) is configuration only
+and is not rebuilt; parameters are plain constructor keywords here.
+
+Besides the reference's per-point ``primitive(t, coords, out)`` both classes
+offer ``primitive_array(t, mesh, i0, i1)``: the same initial data for whole rows
+at once.  The reference fills the array with a Python double loop
+(cbdiso_2d.py:33-46), which is 2.7e8 interpreter calls at 16384^2.
+"""
+from math import exp, pi, sqrt
+
+import numpy as np
+
+from .mesh import PlanarCartesian2DMesh
+from .physics.circumbinary import EquationOfState, PointMass, SinkModel, ViscosityModel
+from .physics.kepler import OrbitalElements
+
+
+class SetupError(Exception):
+    pass
+
+
+class Setup:
+    """Minimal stand-in for the attributes of SetupBase the solvers and driver read."""
+
+    start_time = 0.0
+    reference_time_scale = 1.0
+    default_end_time = None
+    boundary_condition = "outflow"
+
+    def __init__(self, **kwargs):
+        for key, value in kwargs.items():
+            if not hasattr(type(self), key):
+                raise SetupError(f"{type(self).__name__} has no model parameter {key}")
+            setattr(self, key, value)
+        self.validate()
+
+    def validate(self):
+        pass
+
+    def primitive_array(self, t, mesh, i0=0, i1=None, num_fields=None):
+        """Fallback: the reference's per-point loop (exact by construction)."""
+        i1 = mesh.ni if i1 is None else i1
+        out = np.zeros([i1 - i0, mesh.nj, num_fields])
+        for i in range(i0, i1):
+            for j in range(mesh.nj):
+                self.primitive(t, mesh.cell_coordinates(i, j), out[i - i0, j])
+        return out
+
+
+class CircumbinaryDisk(Setup):
+    eos = "isothermal"
+    domain_radius = 12.0
+    mach_number = 10.0
+    eccentricity = 0.0
+    mass_ratio = 1.0
+    sink_rate = 10.0
+    sink_radius = 0.05
+    softening_length = 0.05
+    buffer_is_enabled = True
+    sink_model = "torque_free"
+    initial_sigma = 1.0
+    initial_pressure = 1e-2
+    cooling_coefficient = 0.0
+    alpha = 0.1
+    nu = 0.001
+    constant_softening = True
+    gamma_law_index = 5.0 / 3.0
+    which_diagnostics = "none"
+
+    reference_time_scale = 2.0 * pi
+    default_end_time = 1000.0
+    default_resolution = 512
+
+    def validate(self):
+        if self.eos not in ("isothermal", "gamma-law"):
+            raise SetupError(f"eos must be isothermal or gamma-law, got {self.eos}")
+        if self.which_diagnostics not in ("none", "mdots"):
+            raise SetupError(f"which_diagnostics must be none or mdots, got {self.which_diagnostics}")
+
+    @property
+    def is_isothermal(self):
+        return self.eos == "isothermal"
+
+    @property
+    def is_gamma_law(self):
+        return self.eos == "gamma-law"
+
+    @property
+    def num_fields(self):
+        return 3 if self.is_isothermal else 4
+
+    def primitive(self, t, coords, primitive):
+        """Per-point initial data, circumbinary_disk.py:82-108."""
+        x, y = coords
+        r = sqrt(x * x + y * y)
+        rs = sqrt(x * x + y * y + self.softening_length * self.softening_length)
+        phx = -y / max(r, 1e-12)
+        phy = +x / max(r, 1e-12)
+        if self.is_isothermal:
+            primitive[0] = self.initial_sigma
+            primitive[1] = sqrt(1.0 / rs) * phx
+            primitive[2] = sqrt(1.0 / rs) * phy
+        else:
+            cavity = 0.0001 + 0.9999 * exp(-((1.0 / rs) ** 30))
+            primitive[0] = self.initial_sigma * rs ** (-3.0 / 5.0) * cavity
+            primitive[1] = sqrt(1.0 / rs) * phx
+            primitive[2] = sqrt(1.0 / rs) * phy
+            primitive[3] = self.initial_pressure * rs ** (-3.0 / 2.0) * cavity
+
+    def primitive_array(self, t, mesh, i0=0, i1=None, num_fields=None):
+        """
+        Rows [i0, i1) of the initial data, vectorised.  The isothermal branch uses
+        only + * / sqrt max, all correctly rounded in numpy, so it is bit-identical
+        to the per-point loop (checked in tests).  The gamma-law branch calls
+        pow/exp, where numpy's vector kernels may differ from libm in the last
+        place; small meshes therefore go through the exact per-point loop.
+        """
+        i1 = mesh.ni if i1 is None else i1
+        if self.is_gamma_law and (i1 - i0) * mesh.nj <= (1 << 18):
+            return Setup.primitive_array(self, t, mesh, i0, i1, 4)
+        i = np.arange(i0, i1, dtype=np.float64)[:, None]
+        j = np.arange(mesh.nj, dtype=np.float64)[None, :]
+        x = mesh.x0 + (i + 0.5) * mesh.dx
+        y = mesh.y0 + (j + 0.5) * mesh.dy
+        r2 = x * x + y * y
+        r = np.sqrt(r2)
+        rs = np.sqrt(r2 + self.softening_length * self.softening_length)
+        rc = np.maximum(r, 1e-12)
+        vk = np.sqrt(1.0 / rs)
+        out = np.zeros([i1 - i0, mesh.nj, self.num_fields])
+        out[..., 1] = vk * (-y / rc)
+        out[..., 2] = vk * (+x / rc)
+        if self.is_isothermal:
+            out[..., 0] = self.initial_sigma
+        else:
+            cavity = 0.0001 + 0.9999 * np.exp(-((1.0 / rs) ** 30))
+            out[..., 0] = self.initial_sigma * rs ** (-3.0 / 5.0) * cavity
+            out[..., 3] = self.initial_pressure * rs ** (-3.0 / 2.0) * cavity
+        return out
+
+    def mesh(self, resolution):
+        return PlanarCartesian2DMesh.centered_square(self.domain_radius, resolution)
+
+    @property
+    def physics(self):
+        """circumbinary_disk.py:117-153"""
+        if self.is_isothermal:
+            return dict(
+                eos_type=EquationOfState.LOCALLY_ISOTHERMAL,
+                mach_number=self.mach_number,
+                point_mass_function=self.point_masses,
+                buffer_is_enabled=self.buffer_is_enabled,
+                buffer_driving_rate=100.0,
+                buffer_onset_width=1.0,
+                cooling_coefficient=0.0,
+                constant_softening=self.constant_softening,
+                viscosity_model=ViscosityModel.CONSTANT_NU if self.nu > 0.0 else ViscosityModel.NONE,
+                viscosity_coefficient=self.nu,
+                alpha=0.0,
+                diagnostics=self.diagnostics,
+            )
+        return dict(
+            eos_type=EquationOfState.GAMMA_LAW,
+            gamma_law_index=self.gamma_law_index,
+            point_mass_function=self.point_masses,
+            buffer_is_enabled=self.buffer_is_enabled,
+            buffer_driving_rate=1000.0,
+            buffer_onset_width=0.1,
+            cooling_coefficient=self.cooling_coefficient,
+            constant_softening=self.constant_softening,
+            viscosity_model=ViscosityModel.CONSTANT_ALPHA if self.alpha > 0.0 else ViscosityModel.NONE,
+            viscosity_coefficient=0.0,
+            alpha=self.alpha,
+            diagnostics=self.diagnostics,
+        )
+
+    @property
+    def diagnostics(self):
+        if self.which_diagnostics == "none":
+            return []
+        return [
+            dict(quantity="time"),
+            dict(quantity="mdot", which_mass=1, accretion=True),
+            dict(quantity="mdot", which_mass=2, accretion=True),
+        ]
+
+    @property
+    def solver(self):
+        return "cbdiso_2d" if self.is_isothermal else "cbdgam_2d"
+
+    @property
+    def orbital_elements(self):
+        return OrbitalElements(
+            semimajor_axis=1.0, total_mass=1.0, mass_ratio=self.mass_ratio, eccentricity=self.eccentricity
+        )
+
+    def point_masses(self, time):
+        """circumbinary_disk.py:194-212"""
+        common = dict(
+            softening_length=self.softening_length,
+            sink_model=SinkModel[self.sink_model.upper()],
+            sink_rate=self.sink_rate,
+            sink_radius=self.sink_radius,
+        )
+        return tuple(PointMass(**common, **body._asdict()) for body in self.orbital_elements.orbital_state(time))
+
+
+class CylindricalExplosion(Setup):
+    eos = "isothermal"
+    smooth = 6.0
+
+    default_end_time = 0.3
+    default_resolution = 200
+
+    def validate(self):
+        if self.eos not in ("isothermal", "gamma-law"):
+            raise ValueError(f"eos must be isothermal or gamma-law, got {self.eos}")
+
+    @property
+    def is_isothermal(self):
+        return self.eos == "isothermal"
+
+    @property
+    def num_fields(self):
+        return 3 if self.is_isothermal else 4
+
+    def primitive(self, t, coords, primitive):
+        """simple2d.py:65-79"""
+        x, y = coords
+        r = (x * x + y * y) ** 0.5
+        f = exp(-((r / 0.25) ** self.smooth)) if self.smooth != 0.0 else float(r < 0.25)
+        if self.is_isothermal:
+            primitive[0] = 0.1 + 0.9 * f
+        else:
+            primitive[0] = 0.100 + 0.900 * f
+            primitive[3] = 0.125 + 0.875 * f
+
+    def primitive_array(self, t, mesh, i0=0, i1=None, num_fields=None):
+        return Setup.primitive_array(self, t, mesh, i0, i1, self.num_fields)
+
+    def mesh(self, resolution):
+        return PlanarCartesian2DMesh.centered_square(1.0, resolution)
+
+    @property
+    def physics(self):
+        if self.is_isothermal:
+            return dict(eos_type=EquationOfState.GLOBALLY_ISOTHERMAL, sound_speed=1.0)
+        return dict(eos_type=EquationOfState.GAMMA_LAW, gamma_law_index=5 / 3)
+
+    @property
+    def solver(self):
+        return "cbdiso_2d" if self.is_isothermal else "cbdgam_2d"
+
+
+SETUPS = {"circumbinary-disk": CircumbinaryDisk, "cylindrical-explosion": CylindricalExplosion}
+
+
+def make_setup(name, **model_parameters):
+    try:
+        return SETUPS[name](**model_parameters)
+    except KeyError:
+        raise SetupError(f"no setup named {name}; have {sorted(SETUPS)}")

@@ -1,0 +1,470 @@
+"""
+Machinery shared by the cbdiso_2d and cbdgam_2d solvers in ``hip`` mode.
+
+It reproduces the observable behaviour of the reference's ``Patch`` / ``Solver``
+pairs (``sailfish/solvers/cbdiso_2d.py:49-590``, ``cbdgam_2d.py:46-520``) --
+``Solver.advance(dt)``, ``maximum_wavespeed()``, ``solution``, ``time``, the RK
+schedules, the stage-time formula, slab patches from ``subdivide`` -- with a
+device-resident, fused data flow:
+
+reference, per RK2 step and patch          here
+-----------------------------------------  ------------------------------------
+primitive_to_conserved pass (48 B/zone)    u^n recomputed in-kernel from the
+                                           retained p^n buffer (un_mode 2)
+set_bc: ~12 strided slice copies           outflow edges are index clamps inside
+                                           the kernel; only the 2 contiguous
+                                           halo slabs between patches move
+2 x advance_rk                             2 x fused stage kernel
+wavespeed kernel + xp.max() (40 B/zone)    folded into the last stage's epilogue
+3 state arrays                             2 (RK1/RK2) or 3 (RK3) state arrays
+
+With ``fused=False`` the solver instead drives the reference-named entry points
+in the reference's own order (p2c, set_bc slice copies, advance_rk with
+conserved0, wavespeed array + max): the drop-in path, kept for parity tests and
+for measuring what the fusions buy.
+
+Multi-GPU: one process per GPU under ``torch.distributed`` (RCCL on device,
+gloo in the CPU tests).  Global patch k of ``subdivide(ni, num_patches)`` lives
+on rank ``k * world // num_patches``; halo slabs between ranks travel as
+``isend``/``irecv`` pairs on a side stream while the rows that do not depend on
+them are updated, and dt is a MAX all-reduce of one double.
+"""
+from logging import getLogger
+
+import numpy as np
+
+from ..kernel.library import Library
+from ..kernel.system import execution_context, get_array_module, num_devices, to_host
+from ..mesh import PlanarCartesian2DMesh
+from ..subdivide import concat_on_host, subdivide
+
+logger = getLogger(__name__)
+
+NG = 2  # guard zones per side
+
+
+class HipBackend:
+    """The product backend: libsfhip.so kernels on torch device arrays."""
+
+    mode = "hip"
+
+    def __init__(self, debug=False):
+        self.lib = Library(mode="hip", debug=debug)
+        self.xp = get_array_module("hip")
+
+    def context(self, device_id):
+        return execution_context("hip", device_id)
+
+    def num_devices(self):
+        return num_devices("hip")
+
+
+class Comm:
+    """Thin view of torch.distributed: who am I, and the few collectives the solver needs."""
+
+    def __init__(self, enabled):
+        self.enabled = enabled
+        if enabled:
+            import torch.distributed as dist
+
+            self.dist = dist
+            self.rank = dist.get_rank()
+            self.size = dist.get_world_size()
+        else:
+            self.dist = None
+            self.rank = 0
+            self.size = 1
+
+    @classmethod
+    def auto(cls, distributed=None):
+        if distributed is None:
+            try:
+                import torch.distributed as dist
+
+                distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            except ImportError:
+                distributed = False
+        return cls(bool(distributed))
+
+    def max_scalar(self, tensor):
+        """In-place MAX all-reduce of a one-element tensor (order independent: bit-exact)."""
+        if self.enabled:
+            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.MAX)
+        return tensor
+
+    def gather_arrays(self, local):
+        """All ranks receive the list of every rank's numpy array (checkpoint path only)."""
+        if not self.enabled:
+            return [local]
+        out = [None] * self.size
+        self.dist.all_gather_object(out, local)
+        return out
+
+
+class PatchBase:
+    """
+    One slab of the mesh with its device arrays.
+
+    Mirrors the attributes of the reference's Patch (cbdiso_2d.py:55-94):
+    ``primitive1`` is the current state, ``primitive2`` the other ping-pong
+    buffer, ``time`` / ``time0`` the stage and step-start times, ``xl..yr`` the
+    patch extents from ``mesh.vertex_coordinates``.
+    """
+
+    num_fields = None
+
+    def __init__(self, time, primitive, mesh, index_range, physics, options, backend, context, fused,
+                 first, last, rk_order):
+        i0, i1 = index_range
+        self.index_range = index_range
+        self.mesh = mesh
+        self.lib = backend.lib
+        self.xp = xp = backend.xp
+        self.execution_context = context
+        self.time = self.time0 = time
+        self.shape = (i1 - i0, mesh.shape[1])  # not including guard zones
+        self.physics = physics
+        self.options = options
+        self.fused = fused
+        self.first = first  # touches the lower domain edge in i
+        self.last = last    # touches the upper domain edge in i
+        self.xl, self.yl = mesh.vertex_coordinates(i0, 0)
+        self.xr, self.yr = mesh.vertex_coordinates(i1, mesh.shape[1])
+        self.wavespeed_valid = False
+        with self.execution_context:
+            self.primitive1 = xp.array(primitive)
+            self.primitive2 = xp.array(primitive)
+            self.primitive3 = xp.array(primitive) if (fused and rk_order == 3) else None
+            self.wavespeed_max = xp.zeros(1)
+            if not fused:
+                self.conserved0 = xp.zeros(primitive.shape)
+                self.wavespeeds = xp.zeros(primitive.shape[:2])
+        self._coords = None
+
+    @property
+    def primitive(self):
+        return self.primitive1
+
+    @property
+    def cell_center_coordinate_arrays(self):
+        if self._coords is None:
+            ni, nj = self.shape
+            with self.execution_context:
+                x0 = self.xl + 0.5 * self.mesh.dx
+                x1 = self.xr - 0.5 * self.mesh.dx
+                y0 = self.yl + 0.5 * self.mesh.dy
+                y1 = self.yr - 0.5 * self.mesh.dy
+                self._coords = (self.xp.linspace(x0, x1, ni)[:, None], self.xp.linspace(y0, y1, nj)[None, :])
+        return self._coords
+
+    def stage_time(self, rk_param, dt):
+        """Time after a stage; the reference's expression, literally (cbdiso_2d.py:239)."""
+        return self.time0 * rk_param + (self.time + dt) * (1.0 - rk_param)
+
+    # --- reference-style (unfused) operations -------------------------------
+    def new_iteration(self):
+        self.time0 = self.time
+        if not self.fused:
+            self.recompute_conserved()
+
+    # --- fused stage -----------------------------------------------------------
+    def stage_buffers(self, stage, nstages):
+        """
+        (read, u^n source, write) for stage `stage` of `nstages`.
+
+        After stage 0 the buffers are swapped, so from then on ``primitive1`` is
+        the latest stage result and ``primitive2`` holds p^n.  p^n stays intact
+        until the last stage, whose output overwrites it in place: each zone's
+        u^n is read by the very lane that then writes that zone and by nothing
+        else.  Only RK3's middle stage needs a third buffer.
+        """
+        if stage == 0:
+            return self.primitive1, None, self.primitive2
+        if nstages == 3 and stage == 1:
+            return self.primitive1, self.primitive2, self.primitive3
+        return self.primitive1, self.primitive2, self.primitive2
+
+    def finish_stage(self, rk_param, dt, wrote=None):
+        self.time = self.stage_time(rk_param, dt)
+        if wrote is None or wrote is self.primitive2:
+            self.primitive1, self.primitive2 = self.primitive2, self.primitive1
+        else:
+            self.primitive1, self.primitive3 = self.primitive3, self.primitive1
+
+
+class SolverBase:
+    """Common part of the two Solver classes; see the module docstring."""
+
+    num_cons = None
+    patch_class = None
+    default_rk_order = 2
+
+    def _setup_patches(self, setup, mesh, time, solution, num_patches, mode, backend, fused, distributed,
+                       initial_condition):
+        if type(mesh) is not PlanarCartesian2DMesh:
+            raise ValueError("solver only supports 2D cartesian mesh")
+        if setup.boundary_condition != "outflow":
+            raise ValueError("solver only supports outflow boundary condition")
+        if backend is None:
+            if mode != "hip":
+                raise ValueError(
+                    f"sailfish_amd solvers implement execution mode 'hip' only (got {mode!r}); "
+                    "use the reference for cpu/omp"
+                )
+            backend = HipBackend()
+        self.backend = backend
+        self.mode = backend.mode
+        self.xp = backend.xp
+        self.mesh = mesh
+        self.setup = setup
+        self.num_guard = NG
+        self.fused = fused
+        self.comm = Comm.auto(distributed)
+        ni, nj = mesh.shape
+        nq = self.num_cons
+
+        world = self.comm.size
+        if num_patches is None or num_patches < world:
+            num_patches = world
+        if num_patches % world:
+            raise ValueError(f"num_patches ({num_patches}) must be a multiple of the number of ranks ({world})")
+        per_rank = num_patches // world
+        ranges = subdivide(ni, num_patches)
+        self.num_patches = num_patches
+        self.patch_ranges = ranges
+        self.local_ids = list(range(self.comm.rank * per_rank, (self.comm.rank + 1) * per_rank))
+        self.owner = lambda k: k // per_rank
+
+        logger.info(f"initiate with time={time:0.4f}")
+        logger.info(f"subdivide grid over {num_patches} patches on {world} rank(s)")
+        logger.info(f"mesh is {mesh}")
+
+        ndev = backend.num_devices()
+        if self.comm.enabled and backend.mode == "hip":
+            import os
+
+            base_device = int(os.environ.get("LOCAL_RANK", self.comm.rank % max(ndev, 1)))
+        else:
+            base_device = None
+
+        self.patches = []
+        rk_order = getattr(self._options, "rk_order", self.default_rk_order)
+        for n, k in enumerate(self.local_ids):
+            a, b = ranges[k]
+            prim = np.zeros([b - a + 2 * NG, nj + 2 * NG, nq])
+            if solution is None:
+                prim[NG:-NG, NG:-NG] = initial_condition(setup, mesh, time, a, b)
+            else:
+                prim[NG:-NG, NG:-NG] = solution[a:b]
+            device = base_device if base_device is not None else (n % max(ndev, 1))
+            patch = self.patch_class(
+                time, prim, mesh, (a, b), self._physics, self._options, backend,
+                backend.context(device), fused, first=(k == 0), last=(k == num_patches - 1),
+                rk_order=rk_order, **self._patch_kwargs(),
+            )
+            self.patches.append(patch)
+        self._comm_stream = None
+        self._mass_cache = (None, None)
+
+    def _patch_kwargs(self):
+        return {}
+
+    # ------------------------------------------------------------------ state
+    @property
+    def solution(self):
+        """(ni, nj, NCONS) float64 host array without guards (reference: cbdiso_2d.py:357-361)."""
+        local = concat_on_host([p.primitive for p in self.patches], (NG, NG))
+        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+
+    @property
+    def primitive(self):
+        return None  # as the reference: the solution array is primitive already
+
+    @property
+    def time(self):
+        return self.patches[0].time
+
+    @property
+    def options(self):
+        return self._options._asdict()
+
+    @property
+    def physics(self):
+        return self._physics._asdict()
+
+    @property
+    def maximum_cfl(self):
+        return 0.4
+
+    def point_masses(self, time):
+        """Kepler solve once per distinct time, shared by all local patches."""
+        if self._mass_cache[0] != time:
+            self._mass_cache = (time, self._physics.point_masses(time))
+        return self._mass_cache[1]
+
+    # -------------------------------------------------------------------- dt
+    def maximum_wavespeed(self):
+        """
+        Global max wavespeed (reference: cbdiso_2d.py:525-534 via lazy_reduce).
+        Launch on every patch first, then one device->host read, then the
+        cross-rank MAX.  After a fused step the per-patch maxima are already on
+        the device (epilogue of the last stage) and no kernel runs at all.
+        """
+        for p in self.patches:
+            if not (self.fused and p.wavespeed_valid):
+                with p.execution_context:
+                    p.launch_maximum_wavespeed(self.point_masses(p.time))
+        if len(self.patches) == 1:
+            local = self.patches[0].wavespeed_max
+        else:
+            dev = self.patches[0].wavespeed_max.device
+            local = self.patches[0].wavespeed_max.clone()
+            for p in self.patches[1:]:
+                local = self._torch().maximum(local, p.wavespeed_max.to(dev))
+        if self.comm.enabled:
+            local = local.clone()
+            self.comm.max_scalar(local)
+        return float(local.item())
+
+    def _torch(self):
+        import torch
+
+        return torch
+
+    # --------------------------------------------------------------- advance
+    def rk_parameters(self):
+        order = getattr(self._options, "rk_order", self.default_rk_order)
+        return {1: [0.0], 2: [0.0, 0.5], 3: [0.0, 0.75, 1.0 / 3.0]}[order]
+
+    def advance(self, dt):
+        """One full Runge-Kutta step (reference: cbdiso_2d.py:536-546, cbdgam_2d.py:473-476)."""
+        self.new_iteration()
+        params = self.rk_parameters()
+        for stage, a in enumerate(params):
+            self.advance_rk(a, dt, stage, len(params))
+
+    def new_iteration(self):
+        for p in self.patches:
+            with p.execution_context:
+                p.new_iteration()
+
+    def advance_rk(self, rk_param, dt, stage=0, nstages=1):
+        if not self.fused:
+            self.set_bc("primitive1")
+            for p in self.patches:
+                with p.execution_context:
+                    p.advance_rk(rk_param, dt, self.point_masses(p.time))
+            return
+
+        last_stage = stage == nstages - 1
+        pending = self.start_halo_exchange()
+        plans = []
+        for p in self.patches:
+            ni = p.shape[0]
+            lo = 0 if p.first else min(NG, ni)       # rows [0, lo) need the lower halo
+            hi = ni if p.last else max(ni - NG, lo)  # rows [hi, ni) need the upper halo
+            rd, un, wr = p.stage_buffers(stage, nstages)
+            masses = self.point_masses(p.time)
+            next_masses = self.point_masses(p.stage_time(rk_param, dt)) if last_stage else masses
+            plans.append((p, lo, hi, rd, un, wr, masses, next_masses))
+            with p.execution_context:
+                p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, lo, hi, 2 if last_stage else 0)
+        self.finish_halo_exchange(pending)
+        for p, lo, hi, rd, un, wr, masses, next_masses in plans:
+            ni = p.shape[0]
+            with p.execution_context:
+                if lo > 0:
+                    p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, 0, lo, 1 if last_stage else 0)
+                if hi < ni:
+                    p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, hi, ni, 1 if last_stage else 0)
+            p.finish_stage(rk_param, dt, wr)
+            p.wavespeed_valid = last_stage
+
+    # ----------------------------------------------------------- halo exchange
+    def _neighbors(self, k):
+        return (k - 1 if k > 0 else None), (k + 1 if k < self.num_patches - 1 else None)
+
+    def start_halo_exchange(self, array="primitive1"):
+        """
+        Fill the guard rows between patches (reference: set_bc step 1,
+        cbdiso_2d.py:569-571): each patch's first/last two interior rows go to
+        its lower/upper neighbour's guard rows.  Rows are contiguous, so a halo
+        is a single slab of 2*(nj+4)*NCONS doubles.  Same-process neighbours are
+        a device copy; other ranks get isend/irecv on a side stream so the
+        caller can update halo-independent rows meanwhile.
+        """
+        local = {k: p for k, p in zip(self.local_ids, self.patches)}
+        ops = []
+        for k, p in local.items():
+            lower, upper = self._neighbors(k)
+            pc = getattr(p, array)
+            if lower is not None:
+                if lower in local:
+                    with p.execution_context:
+                        pc[:NG].copy_(getattr(local[lower], array)[-2 * NG:-NG], non_blocking=True)
+                else:
+                    ops.append(("send", pc[NG:2 * NG], self.owner(lower)))
+                    ops.append(("recv", pc[:NG], self.owner(lower)))
+            if upper is not None:
+                if upper in local:
+                    with p.execution_context:
+                        pc[-NG:].copy_(getattr(local[upper], array)[NG:2 * NG], non_blocking=True)
+                else:
+                    ops.append(("send", pc[-2 * NG:-NG], self.owner(upper)))
+                    ops.append(("recv", pc[-NG:], self.owner(upper)))
+        if not ops:
+            return None
+        dist = self.comm.dist
+        torch = self._torch()
+        p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops]
+        if self.backend.mode == "hip":
+            with self.patches[0].execution_context:
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream()
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._comm_stream):
+                    reqs = dist.batch_isend_irecv(p2p)
+            return reqs
+        return dist.batch_isend_irecv(p2p)
+
+    def finish_halo_exchange(self, reqs):
+        if not reqs:
+            return
+        if self.backend.mode == "hip":
+            torch = self._torch()
+            with self.patches[0].execution_context:
+                with torch.cuda.stream(self._comm_stream):
+                    for r in reqs:
+                        r.wait()
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+        else:
+            for r in reqs:
+                r.wait()
+
+    def set_bc(self, array):
+        """
+        Reference-style boundary fill for the unfused path (cbdiso_2d.py:553-586):
+        halos between patches, then outflow copies on the domain edges in i and
+        on both edges in j (which also fills the corners).
+        """
+        self.finish_halo_exchange(self.start_halo_exchange(array))
+        for p in self.patches:
+            pc = getattr(p, array)
+            with p.execution_context:
+                if p.first:
+                    for i in range(NG):
+                        pc[i] = pc[NG]
+                if p.last:
+                    for i in range(pc.shape[0] - NG, pc.shape[0]):
+                        pc[i] = pc[-NG - 1]
+                for j in range(NG):
+                    pc[:, j] = pc[:, NG]
+                for j in range(pc.shape[1] - NG, pc.shape[1]):
+                    pc[:, j] = pc[:, -NG - 1]
+
+    def synchronize(self):
+        if self.backend.mode == "hip":
+            torch = self._torch()
+            for p in self.patches:
+                with p.execution_context:
+                    torch.cuda.synchronize()

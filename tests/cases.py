@@ -1,0 +1,142 @@
+"""
+Seeded kernel-level test problems: random-but-physical primitive data on small
+non-square patches plus every scalar a kernel takes, for each branch combination
+the kernels contain.
+"""
+import itertools
+
+import numpy as np
+
+NG = 2
+
+
+def random_primitive(seed, ni, nj, nq):
+    rng = np.random.default_rng(seed)
+    p = np.empty((ni + 2 * NG, nj + 2 * NG, nq))
+    p[..., 0] = rng.uniform(0.1, 2.0, p.shape[:2])
+    p[..., 1] = rng.uniform(-2.0, 2.0, p.shape[:2])
+    p[..., 2] = rng.uniform(-2.0, 2.0, p.shape[:2])
+    if nq == 4:
+        p[..., 3] = rng.uniform(0.1, 2.0, p.shape[:2])
+    return p
+
+
+def smooth_primitive(ni, nj, nq, extent):
+    """Smooth data (so that slopes are mostly non-zero) on the given extent."""
+    xl, xr, yl, yr = extent
+    x = xl + (np.arange(-NG, ni + NG) + 0.5) * (xr - xl) / ni
+    y = yl + (np.arange(-NG, nj + NG) + 0.5) * (yr - yl) / nj
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    p = np.empty((ni + 2 * NG, nj + 2 * NG, nq))
+    p[..., 0] = 1.0 + 0.3 * np.sin(1.3 * X) * np.cos(0.7 * Y)
+    p[..., 1] = 0.5 * np.cos(0.9 * X + 0.2) - 0.2 * Y
+    p[..., 2] = 0.4 * np.sin(0.5 * Y - 0.1) + 0.1 * X
+    if nq == 4:
+        p[..., 3] = 0.6 + 0.2 * np.cos(0.8 * X) * np.sin(1.1 * Y)
+    return p
+
+
+def mass(x, y, vx, vy, m, rsoft, rate, rsink, model):
+    return (x, y, vx, vy, m, rsoft, rate, rsink, model)
+
+
+NO_MASS = mass(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0)
+
+
+def iso_case(seed=0, ni=32, nj=48, eos=2, nu=0.001, buffer_on=True, sink_model=2, a=0.0, masses=True,
+             smooth=False, extent=(-1.6, 1.6, -2.4, 2.4), sink_rate=10.0, dt=1e-3):
+    """Keyword dict for cbdiso_2d_advance_rk (minus the three arrays) plus the input arrays."""
+    prim = smooth_primitive(ni, nj, 3, extent) if smooth else random_primitive(seed, ni, nj, 3)
+    cons = np.zeros_like(prim)
+    cons[..., 0] = prim[..., 0]
+    cons[..., 1] = prim[..., 1] * prim[..., 0]
+    cons[..., 2] = prim[..., 2] * prim[..., 0]
+    rng = np.random.default_rng(seed + 1000)
+    cons *= rng.uniform(0.9, 1.1, cons.shape)  # u^n differs from p2c(prim) in later stages
+    if masses:
+        m1 = mass(0.31, 0.12, -0.2, 0.6, 0.5, 0.05, sink_rate, 0.2, sink_model)
+        m2 = mass(-0.29, -0.11, 0.2, -0.6, 0.5, 0.05, sink_rate, 0.2, sink_model)
+    else:
+        m1 = m2 = NO_MASS
+    return dict(
+        shape=(ni, nj), extent=extent, prim=prim, cons=cons,
+        buffer=(0.8, m1[4] + m2[4], 100.0, max(abs(extent[1]), abs(extent[3])), 0.5, int(buffer_on)),
+        m1=m1, m2=m2, eos=(1.3, 100.0, eos), nu=nu, a=a, dt=dt, vmax=1e12, dfloor=1e-12,
+    )
+
+
+def iso_advance_args(c, cons, rd, wr):
+    return (*c["extent"], cons, rd, wr, *c["buffer"], *c["m1"], *c["m2"], *c["eos"],
+            c["nu"], c["a"], c["dt"], c["vmax"], c["dfloor"])
+
+
+def iso_wavespeed_args(c, prim, out):
+    return (*c["extent"], *c["eos"], *c["m1"], *c["m2"], prim, out)
+
+
+def iso_branch_matrix():
+    """Every combination exercised by both the oracle-vs-reference and the HIP-vs-oracle tests."""
+    combos = []
+    for eos, nu, buf, model, a in itertools.product((1, 2), (0.0, 0.01), (0, 1), (0, 1, 2, 3), (0.0, 0.5)):
+        combos.append(dict(eos=eos, nu=nu, buffer_on=bool(buf), sink_model=model, a=a))
+    combos.append(dict(a=0.75, smooth=True))
+    combos.append(dict(a=1.0 / 3.0, smooth=True))
+    combos.append(dict(masses=False, eos=1, buffer_on=False, nu=0.0))
+    combos.append(dict(sink_rate=-3.0, sink_model=1))  # negative rate: uniform source branch
+    combos.append(dict(ni=5, nj=3))                    # tiny, ragged
+    combos.append(dict(ni=1, nj=1))
+    combos.append(dict(ni=67, nj=131, smooth=True))    # several strips / not multiples of anything
+    return combos
+
+
+def gam_case(seed=0, ni=32, nj=48, alpha=0.1, buffer_on=True, sink_model=2, a=0.0, masses=True, smooth=False,
+             extent=(-1.6, 1.6, -2.4, 2.4), cooling=0.0, constant_softening=True, dt=1e-3, gamma=5.0 / 3.0):
+    prim = smooth_primitive(ni, nj, 4, extent) if smooth else random_primitive(seed, ni, nj, 4)
+    cons = np.zeros_like(prim)
+    cons[..., 0] = prim[..., 0]
+    cons[..., 1] = prim[..., 1] * prim[..., 0]
+    cons[..., 2] = prim[..., 2] * prim[..., 0]
+    cons[..., 3] = prim[..., 3] / (gamma - 1.0) + 0.5 * prim[..., 0] * (prim[..., 1] ** 2 + prim[..., 2] ** 2)
+    rng = np.random.default_rng(seed + 1000)
+    cons *= rng.uniform(0.95, 1.05, cons.shape)
+    if masses:
+        m1 = mass(0.31, 0.12, -0.2, 0.6, 0.5, 0.05, 10.0, 0.2, sink_model)
+        m2 = mass(-0.29, -0.11, 0.2, -0.6, 0.5, 0.05, 10.0, 0.2, sink_model)
+    else:
+        m1 = m2 = NO_MASS
+    return dict(
+        shape=(ni, nj), extent=extent, prim=prim, cons=cons, gamma=gamma,
+        buffer=(0.8, 0.05, m1[4] + m2[4], 1000.0, max(abs(extent[1]), abs(extent[3])), 0.5, int(buffer_on)),
+        m1=m1, m2=m2, alpha=alpha, a=a, dt=dt, vmax=1e16, cooling=cooling, mach_ceiling=1e5,
+        dfloor=1e-10, pfloor=1e-12, constant_softening=int(constant_softening),
+    )
+
+
+def gam_advance_args(c, cons, rd, wr):
+    return (*c["extent"], cons, rd, wr, c["gamma"], *c["buffer"], *c["m1"], *c["m2"],
+            c["alpha"], c["a"], c["dt"], c["vmax"], c["cooling"], c["mach_ceiling"], c["dfloor"], c["pfloor"],
+            c["constant_softening"])
+
+
+def gam_branch_matrix():
+    combos = []
+    for alpha, buf, model, a in itertools.product((0.0, 0.1), (0, 1), (0, 1, 2, 3), (0.0, 0.5)):
+        combos.append(dict(alpha=alpha, buffer_on=bool(buf), sink_model=model, a=a))
+    combos.append(dict(cooling=1e-2, a=0.5, smooth=True))
+    combos.append(dict(constant_softening=False, a=0.5))
+    combos.append(dict(masses=False, alpha=0.1, buffer_on=False))
+    combos.append(dict(masses=False, alpha=0.0, buffer_on=False, smooth=True))
+    combos.append(dict(ni=5, nj=3))
+    combos.append(dict(ni=1, nj=1))
+    combos.append(dict(ni=67, nj=131, smooth=True))
+    return combos
+
+
+def zone_relative_error(a, b, interior=True):
+    """max over zones of |a-b|_inf / max(|b|_inf over the zone's fields, tiny)."""
+    if interior:
+        a = a[NG:-NG, NG:-NG]
+        b = b[NG:-NG, NG:-NG]
+    num = np.abs(a - b).max(axis=-1)
+    den = np.maximum(np.abs(b).max(axis=-1), 1e-300)
+    return float((num / den).max())
