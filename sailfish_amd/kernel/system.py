@@ -84,12 +84,23 @@ def get_array_module(mode):
     raise ValueError(f"unknown execution mode {mode}, must be one of {MODES}")
 
 
-@contextlib.contextmanager
-def _hip_device(device_id):
-    import torch
+class _HipDevice:
+    """Re-enterable device guard (a patch keeps one and enters it for every launch)."""
 
-    with torch.cuda.device(device_id):
-        yield
+    def __init__(self, device_id):
+        self.device_id = device_id
+        self._stack = []
+
+    def __enter__(self):
+        import torch
+
+        guard = torch.cuda.device(self.device_id)
+        guard.__enter__()
+        self._stack.append(guard)
+        return self
+
+    def __exit__(self, *exc):
+        return self._stack.pop().__exit__(*exc)
 
 
 def execution_context(mode, device_id=None):
@@ -102,7 +113,7 @@ def execution_context(mode, device_id=None):
     if mode == "host":
         return contextlib.nullcontext()
     if mode == "hip":
-        return _hip_device(device_id or 0)
+        return _HipDevice(device_id or 0)
     raise ValueError(f"unknown execution mode {mode}")
 
 

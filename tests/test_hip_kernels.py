@@ -1,0 +1,226 @@
+"""
+GPU parity tests proper: every C-ABI entry point of libsfhip.so against the
+oracle on the same seeded inputs, called the way the reference's Patch classes
+call their kernels (``lib.<name>[shape](*args)``).
+
+Bars (north_star): advance_rk within 1e-12 relative per zone; wavespeed,
+primitive_to_conserved and the max reduction bit-exact.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+ADVANCE_TOL = 1e-12  # relative, per zone (BASELINE.json north_star)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return oracle.oracle()
+
+
+def dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def test_single_hip_runtime_in_process(hip_lib):
+    """libsfhip.so must share torch's HIP runtime, or device pointers/streams would not be interchangeable."""
+    with open("/proc/self/maps") as f:
+        libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+
+
+def test_lane_shift_selftest(hip_lib):
+    import ctypes
+    import torch
+
+    x = torch.arange(64, dtype=torch.float64, device="cuda") * 1.5 + 0.25
+    below = torch.zeros_like(x)
+    above = torch.zeros_like(x)
+    hip_lib.bind_stream([x])
+    assert hip_lib.module.sfhip_selftest_lane_shift(
+        ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(below.data_ptr()), ctypes.c_void_p(above.data_ptr())) == 0
+    xh, b, a = host(x), host(below), host(above)
+    assert np.array_equal(b[1:], xh[:-1]) and b[0] == xh[0]
+    assert np.array_equal(a[:-1], xh[1:]) and a[-1] == xh[-1]
+
+
+@pytest.mark.parametrize("kw", cases.iso_branch_matrix(), ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_iso_advance_rk(hip_lib, orc, kw):
+    c = cases.iso_case(seed=7, **kw)
+    expect = np.full_like(c["prim"], -7.0)
+    orc.call("cbdiso_2d_advance_rk", c["shape"], *cases.iso_advance_args(c, c["cons"], c["prim"], expect))
+    wr = dev(np.full_like(c["prim"], -7.0))
+    hip_lib.cbdiso_2d_advance_rk[c["shape"]](*cases.iso_advance_args(c, dev(c["cons"]), dev(c["prim"]), wr))
+    got = host(wr)
+    assert np.all(got[:2] == -7.0) and np.all(got[-2:] == -7.0)
+    assert np.all(got[:, :2] == -7.0) and np.all(got[:, -2:] == -7.0)  # guards untouched
+    err = cases.zone_relative_error(got, expect)
+    assert err <= ADVANCE_TOL, err
+
+
+@pytest.mark.parametrize("eos", [1, 2])
+@pytest.mark.parametrize("shape", [(40, 23), (1, 1), (3, 300)])
+def test_iso_wavespeed_bit_exact(hip_lib, orc, eos, shape):
+    c = cases.iso_case(seed=3, eos=eos, ni=shape[0], nj=shape[1])
+    expect = np.zeros(c["prim"].shape[:2])
+    orc.call("cbdiso_2d_wavespeed", c["shape"], *cases.iso_wavespeed_args(c, c["prim"], expect))
+    out = dev(np.zeros_like(expect))
+    prim = dev(c["prim"])
+    hip_lib.cbdiso_2d_wavespeed[c["shape"]](*cases.iso_wavespeed_args(c, prim, out))
+    assert np.array_equal(host(out), expect)
+    # the max reduction and the fused max kernel return exactly max(expect)
+    import torch
+
+    m = torch.zeros(1, dtype=torch.float64, device="cuda")
+    hip_lib.sfhip_max_nonneg[out.numel()](out, m)
+    assert float(m.item()) == expect.max()
+    m2 = torch.full((1,), 123.0, dtype=torch.float64, device="cuda")
+    m1_, m2_ = c["m1"], c["m2"]
+    hip_lib.sfhip_cbdiso_2d_max_wavespeed[c["shape"]](
+        *c["extent"], *c["eos"], m1_[0], m1_[1], m1_[4], m1_[5], m2_[0], m2_[1], m2_[4], m2_[5], prim, m2)
+    assert float(m2.item()) == expect.max()
+
+
+def test_iso_p2c_and_rate(hip_lib, orc):
+    c = cases.iso_case(seed=3, ni=40, nj=23)
+    expect = np.zeros_like(c["prim"])
+    orc.call("cbdiso_2d_primitive_to_conserved", c["shape"], c["prim"], expect)
+    out = dev(np.zeros_like(expect))
+    hip_lib.cbdiso_2d_primitive_to_conserved[c["shape"]](dev(c["prim"]), out)
+    assert np.array_equal(host(out), expect)
+
+    expect = np.zeros_like(c["prim"])
+    orc.call("cbdiso_2d_point_mass_source_term", c["shape"], *c["extent"], *c["m1"], c["prim"], expect)
+    out = dev(np.zeros_like(expect))
+    hip_lib.cbdiso_2d_point_mass_source_term[c["shape"]](*c["extent"], *c["m1"], dev(c["prim"]), out)
+    assert cases.zone_relative_error(host(out), expect) <= ADVANCE_TOL
+
+
+def _fill_guards(p, clamp_lo=True, clamp_hi=True):
+    """Reference set_bc on a single patch (cbdiso_2d.py:573-586)."""
+    p = p.copy()
+    if clamp_lo:
+        p[:2] = p[2]
+    if clamp_hi:
+        p[-2:] = p[-3]
+    p[:, :2] = p[:, 2:3]
+    p[:, -2:] = p[:, -3:-2]
+    return p
+
+
+@pytest.mark.parametrize("a", [0.0, 0.5])
+@pytest.mark.parametrize("shape", [(32, 48), (70, 150)])
+def test_iso_fused_stage_equals_reference_sequence(hip_lib, orc, a, shape):
+    """
+    Fused stage (index-clamp boundaries, u^n from p^n, output aliasing p^n,
+    wavespeed epilogue, row-range split) == set_bc + p2c + advance_rk + wavespeed
+    of the oracle.
+    """
+    import torch
+
+    c = cases.iso_case(seed=21, ni=shape[0], nj=shape[1], a=a, smooth=True)
+    ni, nj = c["shape"]
+    pn = cases.random_primitive(99, ni, nj, 3)  # the p^n the step started from
+    cons = np.zeros_like(pn)
+    orc.call("cbdiso_2d_primitive_to_conserved", c["shape"], pn, cons)
+    rd = _fill_guards(c["prim"])
+    expect = np.zeros_like(rd)
+    orc.call("cbdiso_2d_advance_rk", c["shape"], *cases.iso_advance_args(c, cons, rd, expect))
+    w1 = cases.mass(0.3, 0.1, 0, 0, 0.5, 0.05, 0, 0, 0)
+    w2 = cases.mass(-0.3, -0.1, 0, 0, 0.5, 0.05, 0, 0, 0)
+    ws = np.zeros(rd.shape[:2])
+    orc.call("cbdiso_2d_wavespeed", c["shape"], *c["extent"], *c["eos"], *w1, *w2, expect, ws)
+
+    garbage = c["prim"].copy()
+    garbage[:2] = np.nan; garbage[-2:] = np.nan; garbage[:, :2] = np.nan; garbage[:, -2:] = np.nan
+    d_rd = dev(garbage)  # guards must never be read when clamping
+    d_pn = dev(pn)
+    wmax = torch.full((1,), 55.0, dtype=torch.float64, device="cuda")
+    cut1, cut2 = 2, ni - 2
+    for k, (i0, i1) in enumerate([(cut1, cut2), (0, cut1), (cut2, ni)]):
+        hip_lib.sfhip_cbdiso_2d_stage[c["shape"]](
+            *c["extent"], d_pn if a != 0.0 else None, d_rd, d_pn,
+            *c["buffer"], *c["m1"], *c["m2"], *c["eos"], c["nu"], c["a"], c["dt"], c["vmax"], c["dfloor"],
+            2, 1, 1, i0, i1, 2 if k == 0 else 1,
+            w1[0], w1[1], w1[4], w1[5], w2[0], w2[1], w2[4], w2[5], wmax)
+    got = host(d_pn)
+    err = cases.zone_relative_error(got, expect)
+    assert err <= ADVANCE_TOL, err
+    # wavespeed epilogue is evaluated on the kernel's own output: bit-exact w.r.t. that
+    ws_got = np.zeros(rd.shape[:2])
+    orc.call("cbdiso_2d_wavespeed", c["shape"], *c["extent"], *c["eos"], *w1, *w2, got, ws_got)
+    assert float(wmax.item()) == ws_got.max()
+
+
+@pytest.mark.parametrize("kw", cases.gam_branch_matrix(), ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_gam_advance_rk(hip_lib, orc, kw):
+    c = cases.gam_case(seed=11, **kw)
+    expect = np.full_like(c["prim"], -7.0)
+    orc.call("cbdgam_2d_advance_rk", c["shape"], *cases.gam_advance_args(c, c["cons"], c["prim"], expect))
+    wr = dev(np.full_like(c["prim"], -7.0))
+    hip_lib.cbdgam_2d_advance_rk[c["shape"]](*cases.gam_advance_args(c, dev(c["cons"]), dev(c["prim"]), wr))
+    got = host(wr)
+    assert np.all(got[:2] == -7.0) and np.all(got[:, :2] == -7.0)
+    err = cases.zone_relative_error(got, expect)
+    assert err <= ADVANCE_TOL, err
+
+
+def test_gam_wavespeed_p2c_rate(hip_lib, orc):
+    import torch
+
+    c = cases.gam_case(seed=5, ni=40, nj=23)
+    g = c["gamma"]
+    prim = dev(c["prim"])
+    expect = np.zeros(c["prim"].shape[:2])
+    orc.call("cbdgam_2d_wavespeed", c["shape"], c["prim"], expect, g)
+    out = dev(np.zeros_like(expect))
+    hip_lib.cbdgam_2d_wavespeed[c["shape"]](prim, out, g)
+    assert np.array_equal(host(out), expect)
+    m = torch.zeros(1, dtype=torch.float64, device="cuda")
+    hip_lib.sfhip_cbdgam_2d_max_wavespeed[c["shape"]](prim, g, m)
+    assert float(m.item()) == expect.max()
+
+    expect = np.zeros_like(c["prim"])
+    orc.call("cbdgam_2d_primitive_to_conserved", c["shape"], c["prim"], expect, g)
+    out = dev(np.zeros_like(expect))
+    hip_lib.cbdgam_2d_primitive_to_conserved[c["shape"]](prim, out, g)
+    assert np.array_equal(host(out), expect)
+
+    for which in (1, 2):
+        expect = np.zeros_like(c["prim"])
+        orc.call("cbdgam_2d_point_mass_source_term", c["shape"], *c["extent"], *c["m1"], *c["m2"], which,
+                 c["prim"], expect, 0, g)
+        out = dev(np.zeros_like(expect))
+        hip_lib.cbdgam_2d_point_mass_source_term[c["shape"]](*c["extent"], *c["m1"], *c["m2"], which, prim, out, 0, g)
+        assert cases.zone_relative_error(host(out), expect) <= ADVANCE_TOL
+
+
+def test_boundary_errors(hip_lib):
+    """Kernel[shape] rank check and debug-mode validation behave like the reference's Library."""
+    import torch
+
+    from sailfish_amd.kernel.library import KernelError
+
+    with pytest.raises(ValueError):
+        hip_lib.cbdiso_2d_primitive_to_conserved[(4,)]
+    p = torch.zeros(8, 8, 3, dtype=torch.float64, device="cuda")
+    with pytest.raises(TypeError):
+        hip_lib.cbdiso_2d_primitive_to_conserved[(4, 4)](p)  # arg count
+    with pytest.raises(TypeError):
+        hip_lib.cbdiso_2d_primitive_to_conserved[(4, 4)](p, p.float())  # dtype
+    with pytest.raises(ValueError):
+        hip_lib.cbdiso_2d_primitive_to_conserved[(5, 4)](p, p.clone())  # shape constraint
+    with pytest.raises(KernelError):  # rd/wr aliasing is refused by the library itself
+        c = cases.iso_case()
+        d = dev(c["prim"])
+        hip_lib.cbdiso_2d_advance_rk[c["shape"]](*cases.iso_advance_args(c, dev(c["cons"]), d, d))
