@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""
+bench.py -- zone-updates/sec of the cbdiso_2d hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is what the reference's driver does per iteration (driver.py:508-511):
+dt from the max-wavespeed reduction, then one full RK2 ``solver.advance(dt)``.
+Workload: BASELINE.json configs[1], the circumbinary-disk setup at 4096^2 fp64
+on one MI355X (single patch).  For N > 1 the per-GPU work is held at 4096^2
+zones (weak scaling): the square mesh grows to 4096*sqrt(N) per side and is cut
+into N slab patches, one per rank, with halo slabs and the dt MAX all-reduce on
+RCCL.  Initial data are the setup's analytic disk (no RNG, no files): resident
+in HBM before the clock starts.
+
+Output (rank 0): ONE JSON line with the driver's contract fields plus
+  roofline     -- the stage kernel's achieved algorithmic GB/s against HBM peak,
+                  launch durations measured with HIP events inside the timed region
+  cpu_baseline -- the reference's own C/OpenMP kernels (oracle/_ref, built from
+                  /root/reference by oracle/build_ref.py) or, where absent, our
+                  C port (oracle/sf_oracle.c), driven in the reference's order
+                  on a bounded sample of the same workload (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_STAGE_NO_UN = 48.0  # read p, write p' (3 fp64 each)            SURVEY.md 8(d)
+BYTES_STAGE_UN = 72.0     # + read u^n source at the zone centre      SURVEY.md 8(d)
+BYTES_PER_ZONE_UPDATE = 120.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--resolution", type=int, default=None, help="zones per side (default 4096*sqrt(gpus))")
+    ap.add_argument("--solver", default="iso", choices=["iso", "gam"])
+    ap.add_argument("--unfused", action="store_true", help="drive the reference-named kernels in reference order")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
+    return ap.parse_args()
+
+
+def default_resolution(gpus):
+    n = 4096.0 * math.sqrt(gpus)
+    return int(n // 8) * 8
+
+
+def cpu_baseline(setup_kwargs, resolution, target_seconds):
+    """Time the reference's CPU path (or our port of it) on a few steps of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as test_oracle
+    import ref_solver
+    from sailfish_amd.setups import make_setup
+
+    setup = make_setup("circumbinary-disk", **setup_kwargs)
+    mesh = setup.mesh(resolution)
+    lib = test_oracle.ref(setup.solver, "omp")
+    kind = "reference"
+    if lib is None:
+        lib = test_oracle.oracle()
+        kind = "port"
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    solver = ref_solver.OracleSolver(setup, mesh, time=0.0, lib=lib)
+    cfl = 0.3 if setup.solver == "cbdiso_2d" else 0.1
+
+    def step():
+        dt = mesh.min_spacing() / solver.maximum_wavespeed() * cfl
+        solver.advance(dt)
+
+    step()  # warm-up (page faults, OpenMP team start)
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    n = max(2, min(30, int(target_seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    seconds = time.perf_counter() - t0
+    return dict(
+        value=mesh.num_total_zones * n / seconds * 1e-6,
+        unit="Mzps",
+        cores=cores,
+        kind=kind,
+        sample=f"{n} RK2 steps (p2c + set_bc + 2 advance_rk + wavespeed/max, reference order) of the "
+               f"{resolution}^2 circumbinary-disk workload, OpenMP on {cores} threads, {seconds:.1f} s",
+    )
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sailfish_amd.driver import timestep
+    from sailfish_amd.setups import make_setup
+    from sailfish_amd.solvers import make_solver
+
+    resolution = args.resolution or default_resolution(args.gpus)
+    setup_kwargs = dict(eos="isothermal" if args.solver == "iso" else "gamma-law")
+    setup = make_setup("circumbinary-disk", **setup_kwargs)
+    mesh = setup.mesh(resolution)
+    solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0,
+                         num_patches=world, mode="hip", fused=not args.unfused)
+    cfl = solver.recommended_cfl
+
+    def step():
+        dt = timestep(mesh, solver, cfl)
+        solver.advance(dt)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    use_events = not args.no_events and not args.unfused
+    if use_events:
+        solver.event_log = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    seconds = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t.item())
+
+    zones = mesh.num_total_zones
+    mzps = zones * args.steps / seconds * 1e-6
+
+    roofline = None
+    kernel_ms = None
+    if use_events and solver.event_log:
+        alg_bytes = 0.0
+        dur_ms = 0.0
+        per_kind = {False: [0.0, 0], True: [0.0, 0]}
+        for e in solver.event_log:
+            ms = e["start"].elapsed_time(e["stop"])
+            dur_ms += ms
+            alg_bytes += e["zones"] * (BYTES_STAGE_UN if e["reads_un"] else BYTES_STAGE_NO_UN)
+            per_kind[e["reads_un"]][0] += ms
+            per_kind[e["reads_un"]][1] += 1
+        achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            key = f"{setup.solver}_{resolution}_{world}"
+            traffic = tj.get(key)
+        roofline = dict(
+            bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+            kernel="sf::iso_stage_kernel" if args.solver == "iso" else "sf::gam_stage_kernel",
+            launches=len(solver.event_log),
+            avg_launch_ms=round(dur_ms / len(solver.event_log), 4),
+            algorithmic_bytes_per_launch=round(alg_bytes / len(solver.event_log)),
+        )
+        kernel_ms = {
+            "stage_a0_ms": round(per_kind[False][0] / max(per_kind[False][1], 1), 4),
+            "stage_un_ms": round(per_kind[True][0] / max(per_kind[True][1], 1), 4),
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(setup_kwargs, resolution, args.cpu_seconds)
+        except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
+            cpu = dict(value=None, unit="Mzps", cores=0, kind="port", sample=f"failed: {exc!r}")
+
+    if rank == 0:
+        bytes_per_update = BYTES_PER_ZONE_UPDATE if args.solver == "iso" else 160.0
+        line = {
+            "metric": "zone-updates/sec (Mzps) fp64, cbdiso_2d" if args.solver == "iso" else "zone-updates/sec (Mzps) fp64, cbdgam_2d",
+            "value": round(mzps, 2),
+            "unit": "Mzps",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(seconds / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{setup.solver} circumbinary-disk {resolution}^2 fp64, RK2, "
+                            f"{world} slab patch(es), one per GPU; dt recomputed every step",
+                "zones": zones,
+                "zones_per_gpu": zones // world,
+                "path": "reference-order kernels" if args.unfused else "fused stage kernels",
+            },
+            "hbm_roofline_frac_whole_step": round(mzps * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if kernel_ms:
+            line["kernel_ms"] = kernel_ms
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -265,6 +265,7 @@ class SolverBase:
             self.patches.append(patch)
         self._comm_stream = None
         self._mass_cache = (None, None)
+        self.event_log = None  # bench.py sets this to a list to time every stage launch with HIP events
 
     def _patch_kwargs(self):
         return {}
@@ -368,17 +369,30 @@ class SolverBase:
             next_masses = self.point_masses(p.stage_time(rk_param, dt)) if last_stage else masses
             plans.append((p, lo, hi, rd, un, wr, masses, next_masses))
             with p.execution_context:
-                p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, lo, hi, 2 if last_stage else 0)
+                self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, lo, hi, 2 if last_stage else 0)
         self.finish_halo_exchange(pending)
         for p, lo, hi, rd, un, wr, masses, next_masses in plans:
             ni = p.shape[0]
             with p.execution_context:
                 if lo > 0:
-                    p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, 0, lo, 1 if last_stage else 0)
+                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, 0, lo, 1 if last_stage else 0)
                 if hi < ni:
-                    p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, hi, ni, 1 if last_stage else 0)
+                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, hi, ni, 1 if last_stage else 0)
             p.finish_stage(rk_param, dt, wr)
             p.wavespeed_valid = last_stage
+
+    def _launch(self, p, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed):
+        """One stage-kernel launch on patch `p`, optionally bracketed by HIP events on its stream."""
+        if self.event_log is None:
+            p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed)
+            return
+        torch = self._torch()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed)
+        e1.record()
+        self.event_log.append(dict(zones=(i_end - i_begin) * p.shape[1], reads_un=un is not None, start=e0, stop=e1))
 
     # ----------------------------------------------------------- halo exchange
     def _neighbors(self, k):
