@@ -45,6 +45,14 @@ int sfhip_synchronize(void);        /* hipStreamSynchronize on the current strea
 const char *sfhip_last_error(void); /* thread-local message of the last failing call */
 int sfhip_selftest_lane_shift(const double *in64, double *out_below64, double *out_above64);
 
+/* Device self test of the fast reciprocal / rsqrt / sqrt used by the stage
+ * kernels: out3n = [1/x | 1/sqrt(x) | sqrt(x)] for n positive inputs. */
+SFHIP_API int sfhip_selftest_fastmath(
+    int n,
+    double *x, // :: $.numel() >= n
+    double *out3n) // :: $.numel() >= 3 * n
+;
+
 /* Replaces `self.wavespeeds.max()` (cbdiso_2d.py:174, cbdgam_2d.py:152): max of
  * n non-negative doubles into *out (device scalar). */
 SFHIP_API int sfhip_max_nonneg(

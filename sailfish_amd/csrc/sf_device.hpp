@@ -50,18 +50,55 @@ __device__ __forceinline__ double max2(double a, double b) { return a > b ? a : 
 // Generalised minmod slope, cbdiso_2d.c:23-29 / cbdgam_2d.c:27-33.
 // The reference's 0.25*|sgn a + sgn b|*(sgn a + sgn c)*min|.| is +-min when the
 // three sign bits agree and a signed zero otherwise; all factors are powers of
-// two, so selecting on the sign bits gives the identical value.
+// two, so selecting on the sign bits gives the identical value.  theta > 0 and
+// rounding is monotone, so min(|theta d1|, |theta d2|) == theta min(|d1|, |d2|).
 template <int THETA10> // theta * 10 as an integer template constant
 __device__ __forceinline__ double plm(double yl, double y0, double yr)
 {
     constexpr double theta = THETA10 / 10.0;
-    double a = (y0 - yl) * theta;
+    double d1 = y0 - yl;
+    double d2 = yr - y0;
     double b = (yr - yl) * 0.5;
-    double c = (yr - y0) * theta;
-    double m = min2(fabs(a), min2(fabs(b), fabs(c)));
-    int sa = __double2hiint(a), sb = __double2hiint(b), sc = __double2hiint(c);
+    double m = __builtin_fmin(__builtin_fmin(fabs(d1), fabs(d2)) * theta, fabs(b));
+    int sa = __double2hiint(d1), sb = __double2hiint(b), sc = __double2hiint(d2);
     bool same = ((sa ^ sb) | (sa ^ sc)) >= 0; // sign bit clear <=> all three signs equal
-    return same ? copysign(m, a) : 0.0;
+    return same ? copysign(m, d1) : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// Fast fp64 reciprocal / reciprocal square root.  IEEE fp64 division and sqrt
+// expand to ~11-12 VALU instructions each on CDNA; the stage kernels are
+// VALU-bound and the reference evaluates ~40 of them per zone, so the hot path
+// uses the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-23 relative) plus Newton
+// steps in FMA form instead.  Results are within ~1 ulp (checked on the device
+// by tests/test_hip_kernels.py::test_fast_math_accuracy), far inside the 1e-12
+// parity budget.  The wavespeed / dt path does NOT use these: it stays on
+// correctly rounded division and sqrt so that dt is bit-exact.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// 1/sqrt(x), x > 0: one cubically convergent step, y (1 + e/2 + 3 e^2/8), e = 1 - x y^2
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    double t = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y * e, t, y);
+}
+
+// sqrt(x) from y ~ 1/sqrt(x): s = x y corrected once with its own residual
+__device__ __forceinline__ double sqrt_from_rsqrt(double x, double y)
+{
+    double s = x * y;
+    double r = __builtin_fma(-s, s, x);
+    return __builtin_fma(r, 0.5 * y, s);
 }
 
 // max of a non-negative double over the wave, result valid in every lane

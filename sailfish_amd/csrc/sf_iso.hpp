@@ -22,14 +22,18 @@ namespace sf {
 struct IsoParams {
     int ni, nj;                 // interior zones of the patch
     double xl, yl, dx, dy;      // patch origin and spacing (dx = (xr-xl)/ni on the host, cbdiso_2d.c:440)
+    double inv_dx, inv_dy;      // 1/dx, 1/dy (host, correctly rounded)
     Mass m[2];                  // point masses at the stage time
-    // Keplerian buffer (cbdiso_2d.c:213-246); onset radius and outer orbital
-    // frequency depend only on scalars and are evaluated once on the host with
-    // the same libm calls the reference makes per zone.
+    // Keplerian buffer (cbdiso_2d.c:213-246); everything that depends only on
+    // scalars is evaluated once on the host with the libm calls the reference
+    // makes per zone.
     double buf_sd, buf_mc, buf_rate, buf_rout, buf_ron, buf_omega;
+    double buf_ron2, buf_rate_scale; // ron^2 and rate*omega/(rout-ron)
     int buf_on;
     int eos;                    // 1 globally, 2 locally isothermal (cbdiso_2d.c:194-211)
+    int eos_local;              // eos == 2 and at least one mass > 0: cs2 varies in space
     double cs2, mach2;
+    double cs2_uniform, cs_uniform, inv_mach2; // used when !eos_local / eos_local
     double nu, a, dt, vmax, dfloor;
     // fusion / boundary flags
     int clamp_ilo, clamp_ihi;   // patch touches the domain edge in i: clamp instead of reading guards
@@ -40,6 +44,8 @@ struct IsoParams {
     int want_wavespeed;         // fold max wavespeed of the OUTPUT state into *wmax
     Mass mw[2];                 // masses at the time the output state belongs to (for want_wavespeed)
 };
+
+// ---- exact (IEEE op-for-op) pieces: wavespeed / dt path ----------------------
 
 // softened potential, cbdiso_2d.c:70-95
 __device__ __forceinline__ double iso_potential(const Mass *m, double x, double y)
@@ -65,79 +71,106 @@ __device__ __forceinline__ double iso_cs2(const IsoParams &P, const Mass *m, dou
     return 1.0;
 }
 
+// ---- fast pieces: the stage kernel (within ~1 ulp of the above) -------------
+
+// cs2 and cs at a point for the locally isothermal EOS: cs2 = sum m/sqrt(r^2+rs^2) / M^2.
+// `c0`, `c1` are the lane-invariant parts (y - y_p)^2 + rs_p^2 of the two masses.
+__device__ __forceinline__ void iso_sound_fast(const IsoParams &P, const Mass *m, double x, double c0, double c1,
+                                               double &cs2, double &cs)
+{
+#pragma clang fp contract(fast)
+    if (!P.eos_local) { cs2 = P.cs2_uniform; cs = P.cs_uniform; return; }
+    double q = 0.0;
+    if (m[0].mass > 0.0) { double d = x - m[0].x; q += m[0].mass * fast_rsqrt(d * d + c0); }
+    if (m[1].mass > 0.0) { double d = x - m[1].x; q += m[1].mass * fast_rsqrt(d * d + c1); }
+    cs2 = q * P.inv_mach2;
+    cs = sqrt_from_rsqrt(cs2, fast_rsqrt(cs2));
+}
+
 // HLLE flux through one face, cbdiso_2d.c:285-380.  DIR 0: x-face, 1: y-face.
 template <int DIR>
-__device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, double cs2, double *f)
+__device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, double cs2, double cs, double *f)
 {
-    double ul0 = pl[0], ul1 = pl[1] * pl[0], ul2 = pl[2] * pl[0];
-    double ur0 = pr[0], ur1 = pr[1] * pr[0], ur2 = pr[2] * pr[0];
+#pragma clang fp contract(fast)
+    double ul1 = pl[1] * pl[0], ul2 = pl[2] * pl[0];
+    double ur1 = pr[1] * pr[0], ur2 = pr[2] * pr[0];
     double vl = pl[1 + DIR], vr = pr[1 + DIR];
     double prl = pl[0] * cs2, prr = pr[0] * cs2;
-    double fl0 = vl * ul0, fr0 = vr * ur0;
+    double fl0 = vl * pl[0], fr0 = vr * pr[0];
     double fl1 = vl * ul1, fr1 = vr * ur1;
     double fl2 = vl * ul2, fr2 = vr * ur2;
     if (DIR == 0) { fl1 += prl; fr1 += prr; }
     else          { fl2 += prl; fr2 += prr; }
-    double cs = sqrt(cs2);
-    double am = min2(0.0, min2(vl - cs, vr - cs));
-    double ap = max2(0.0, max2(vl + cs, vr + cs));
-    double den = ap - am;
-    f[0] = (fl0 * ap - fr0 * am - (ul0 - ur0) * ap * am) / den;
-    f[1] = (fl1 * ap - fr1 * am - (ul1 - ur1) * ap * am) / den;
-    f[2] = (fl2 * ap - fr2 * am - (ul2 - ur2) * ap * am) / den;
+    double am = __builtin_fmin(0.0, __builtin_fmin(vl - cs, vr - cs));
+    double ap = __builtin_fmax(0.0, __builtin_fmax(vl + cs, vr + cs));
+    double rden = fast_rcp(ap - am);
+    double apam = ap * am;
+    f[0] = (fl0 * ap - fr0 * am - (pl[0] - pr[0]) * apam) * rden;
+    f[1] = (fl1 * ap - fr1 * am - (ul1 - ur1) * apam) * rden;
+    f[2] = (fl2 * ap - fr2 * am - (ul2 - ur2) * apam) * rden;
 }
 
 // One point mass: gravity + sink, cbdiso_2d.c:97-175.  Accumulates into dc.
-__device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double y1, double dt,
+// `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed.
+__device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double ddy, double cy, double dt,
                                                 const double *prim, double *dc)
 {
+#pragma clang fp contract(fast)
     double sigma = prim[0];
     double ddx = x1 - m.x;
-    double ddy = y1 - m.y;
-    double r2 = ddx * ddx + ddy * ddy;
-    double dr = sqrt(r2);
-    double r2s = r2 + m.rsoft * m.rsoft;
-    // pow(r2s, -1.5) of the reference; 1/(r2s*sqrt(r2s)) agrees to ~1 ulp
-    double fnum = sigma * m.mass * (1.0 / (r2s * sqrt(r2s)));
-    dc[1] += (-fnum * ddx) * dt;
-    dc[2] += (-fnum * ddy) * dt;
-    if (dr < 4.0 * m.sink_radius) { // lazily evaluated like the C ternary: r_sink == 0 never divides
-        double q = dr / m.sink_radius;
-        double q2 = q * q;
-        double rate = m.sink_rate * exp(-(q2 * q2));
-        double mdot = 0.0;
-        if (rate > 0.0) mdot = -rate * sigma;
-        else if (rate < 0.0) mdot = -rate;
-        if (m.sink_model == 1) {
-            dc[0] += dt * mdot;
-            dc[1] += dt * mdot * prim[1];
-            dc[2] += dt * mdot * prim[2];
-        } else if (m.sink_model == 2) {
-            double rhx = ddx / (dr + 1e-12);
-            double rhy = ddy / (dr + 1e-12);
-            double dv = (prim[1] - m.vx) * rhx + (prim[2] - m.vy) * rhy;
-            double vxs = dv * rhx + m.vx;
-            double vys = dv * rhy + m.vy;
-            dc[0] += dt * mdot;
-            dc[1] += dt * mdot * vxs;
-            dc[2] += dt * mdot * vys;
-        } else if (m.sink_model == 3) {
-            dc[0] += dt * mdot;
+    double r2s = ddx * ddx + cy;
+    double y = fast_rsqrt(r2s);
+    double fnum = sigma * m.mass * (y * y * y) * dt; // pow(r^2 + rs^2, -1.5) of the reference
+    dc[1] -= fnum * ddx;
+    dc[2] -= fnum * ddy;
+    double rs4 = 4.0 * m.sink_radius;
+    if (r2s < rs4 * rs4 + m.rsoft * m.rsoft) { // superset of dr < 4 r_sink; exact test inside
+        double r2 = ddx * ddx + ddy * ddy;
+        double dr = sqrt(r2);
+        if (dr < rs4) { // lazily evaluated like the C ternary: r_sink == 0 never divides
+            double q = dr / m.sink_radius;
+            double q2 = q * q;
+            double rate = m.sink_rate * exp(-(q2 * q2));
+            double mdot = 0.0;
+            if (rate > 0.0) mdot = -rate * sigma;
+            else if (rate < 0.0) mdot = -rate;
+            if (m.sink_model == 1) {
+                dc[0] += dt * mdot;
+                dc[1] += dt * mdot * prim[1];
+                dc[2] += dt * mdot * prim[2];
+            } else if (m.sink_model == 2) {
+                double rinv = 1.0 / (dr + 1e-12);
+                double rhx = ddx * rinv;
+                double rhy = ddy * rinv;
+                double dv = (prim[1] - m.vx) * rhx + (prim[2] - m.vy) * rhy;
+                double vxs = dv * rhx + m.vx;
+                double vys = dv * rhy + m.vy;
+                dc[0] += dt * mdot;
+                dc[1] += dt * mdot * vxs;
+                dc[2] += dt * mdot * vys;
+            } else if (m.sink_model == 3) {
+                dc[0] += dt * mdot;
+            }
         }
     }
 }
 
 // Keplerian buffer, cbdiso_2d.c:213-246
-__device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double yc, const double *u, double *dc)
+__device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double yc, double yc2, const double *u, double *dc)
 {
+#pragma clang fp contract(fast)
     if (!P.buf_on) return;
-    double rc = sqrt(xc * xc + yc * yc);
-    if (rc > P.buf_ron) {
-        double vk = sqrt(P.buf_mc / rc);
-        double u0[3] = {P.buf_sd, P.buf_sd * (-yc / rc) * vk, P.buf_sd * (+xc / rc) * vk};
-        double br = P.buf_rate * P.buf_omega * (rc - P.buf_ron) / (P.buf_rout - P.buf_ron);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) dc[q] -= (u[q] - u0[q]) * br * P.dt;
+    double rc2 = xc * xc + yc2;
+    if (rc2 > P.buf_ron2) {
+        double rinv = fast_rsqrt(rc2);
+        double rc = sqrt_from_rsqrt(rc2, rinv);
+        double vk2 = P.buf_mc * rinv;                           // central_mass / rc
+        double vk = sqrt_from_rsqrt(vk2, fast_rsqrt(vk2));
+        double pk = P.buf_sd * vk * rinv;                       // sigma v_kep / rc
+        double br = P.buf_rate_scale * (rc - P.buf_ron) * P.dt; // driving_rate omega (rc-ron)/(rout-ron) dt
+        dc[0] -= (u[0] - P.buf_sd) * br;
+        dc[1] -= (u[1] + pk * yc) * br;
+        dc[2] -= (u[2] - pk * xc) * br;
     }
 }
 
@@ -146,10 +179,12 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 // grid: 1-D, 256 threads = 4 waves; wave w of the grid owns column strip
 // (w % nstrips) and row chunk (w / nstrips).
 // ---------------------------------------------------------------------------
+template <bool WS>
 __global__ __launch_bounds__(256) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
+#pragma clang fp contract(fast)
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int strip = gw % nstrips;
@@ -176,10 +211,25 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
     if (I1 > NG + P.i_end) I1 = NG + P.i_end;
     const int rlo = P.clamp_ilo ? NG : 0;
     const int rhi = P.clamp_ihi ? ni + NG - 1 : ni + 2 * NG - 1;
+    const bool visc = P.nu > 0.0;
+    const double hnu = 0.5 * P.nu;
+    // lane-invariant pieces of the distances to the two masses
+    const double dyc0 = yc - P.m[0].y, dyc1 = yc - P.m[1].y;
+    const double cyc0 = dyc0 * dyc0 + P.m[0].rsoft * P.m[0].rsoft;
+    const double cyc1 = dyc1 * dyc1 + P.m[1].rsoft * P.m[1].rsoft;
+    const double cyf0 = (yf - P.m[0].y) * (yf - P.m[0].y) + P.m[0].rsoft * P.m[0].rsoft;
+    const double cyf1 = (yf - P.m[1].y) * (yf - P.m[1].y) + P.m[1].rsoft * P.m[1].rsoft;
+    const double yc2 = yc * yc;
+    double cyw0 = 0, cyw1 = 0;
+    if (WS) {
+        cyw0 = (yc - P.mw[0].y) * (yc - P.mw[0].y) + P.mw[0].rsoft * P.mw[0].rsoft;
+        cyw1 = (yc - P.mw[1].y) * (yc - P.mw[1].y) + P.mw[1].rsoft * P.mw[1].rsoft;
+    }
+    const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
 
-    double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0}, pc[3];
+    double pa[3] = {1, 0, 0}, pb[3] = {1, 0, 0}, pc[3];
     double gyb[3] = {0, 0, 0};
-    double pmx[3] = {0, 0, 0}, txx = 0, txy = 0;
+    double pmx[3] = {1, 0, 0}, txx = 0, txy = 0;
     double Fp[3] = {0, 0, 0}, dGp[3] = {0, 0, 0};
     double amax = 0.0;
 
@@ -199,9 +249,13 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
             double gxb[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) gxb[q] = plm<18>(pa[q], pb[q], pc[q]);
-            double sxx = 4.0 / 3.0 * gxb[1] / P.dx - 2.0 / 3.0 * gyb[2] / P.dy;
-            double syy = -2.0 / 3.0 * gxb[1] / P.dx + 4.0 / 3.0 * gyb[2] / P.dy;
-            double sxy = gxb[2] / P.dx + gyb[1] / P.dy;
+            double sxx = 0, syy = 0, sxy = 0;
+            if (visc) {
+                double ax = gxb[1] * P.inv_dx, by = gyb[2] * P.inv_dy;
+                sxx = c43 * ax - c23 * by;
+                syy = c43 * by - c23 * ax;
+                sxy = gxb[2] * P.inv_dx + gyb[1] * P.inv_dy;
+            }
 
             double F[3] = {0, 0, 0}, dG[3] = {0, 0, 0};
             const double xf = P.xl + (double)(r - 1 - NG) * P.dx;       // lower x-face of row r-1
@@ -209,28 +263,30 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
 
             if (r >= I0 + 1) {
                 // x-face between rows r-2 and r-1 (cbdiso_2d.c:536-541, 560-561, 579-582)
-                double ppx[3];
+                double ppx[3], c2, cs;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - 0.5 * gxb[q];
-                iso_hlle<0>(pmx, ppx, iso_cs2(P, P.m, xf, yc), F);
-                if (P.nu > 0.0) {
-                    F[1] -= 0.5 * P.nu * (txx + pb[0] * sxx);
-                    F[2] -= 0.5 * P.nu * (txy + pb[0] * sxy);
+                iso_sound_fast(P, P.m, xf, cyc0, cyc1, c2, cs);
+                iso_hlle<0>(pmx, ppx, c2, cs, F);
+                if (visc) {
+                    F[1] -= hnu * (txx + pb[0] * sxx);
+                    F[2] -= hnu * (txy + pb[0] * sxy);
                 }
             }
             if (r - 1 >= I0 && r - 1 < I1) {
                 // y-face below this lane's zone in row r-1 (cbdiso_2d.c:543-546, 562-563, 583-586)
-                double pmy[3], ppy[3], G[3];
+                double pmy[3], ppy[3], G[3], c2, cs;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     pmy[q] = from_lane_below(pb[q] + 0.5 * gyb[q]);
                     ppy[q] = pb[q] - 0.5 * gyb[q];
                 }
-                iso_hlle<1>(pmy, ppy, iso_cs2(P, P.m, xcb, yf), G);
-                if (P.nu > 0.0) {
+                iso_sound_fast(P, P.m, xcb, cyf0, cyf1, c2, cs);
+                iso_hlle<1>(pmy, ppy, c2, cs, G);
+                if (visc) {
                     double tyx = pb[0] * sxy, tyy = pb[0] * syy;
-                    G[1] -= 0.5 * P.nu * (from_lane_below(tyx) + tyx);
-                    G[2] -= 0.5 * P.nu * (from_lane_below(tyy) + tyy);
+                    G[1] -= hnu * (from_lane_below(tyx) + tyx);
+                    G[2] -= hnu * (from_lane_below(tyy) + tyy);
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) dG[q] = from_lane_above(G[q]) - G[q];
@@ -240,31 +296,43 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
                 const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
                 double u[3] = {pa[0], pa[1] * pa[0], pa[2] * pa[0]};
                 double dc[3] = {0.0, 0.0, 0.0};
-                iso_buffer(P, xc, yc, u, dc);
-                iso_mass_source(P.m[0], xc, yc, P.dt, pa, dc);
-                iso_mass_source(P.m[1], xc, yc, P.dt, pa, dc);
+                iso_buffer(P, xc, yc, yc2, u, dc);
+                iso_mass_source(P.m[0], xc, dyc0, cyc0, P.dt, pa, dc);
+                iso_mass_source(P.m[1], xc, dyc1, cyc1, P.dt, pa, dc);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    dc[q] -= ((F[q] - Fp[q]) / P.dx + dGp[q] / P.dy) * P.dt;
+                    dc[q] -= ((F[q] - Fp[q]) * P.inv_dx + dGp[q] * P.inv_dy) * P.dt;
                     u[q] += dc[q];
                 }
                 const long c = (long)(r - 2) * si + (long)J * sj;
                 if (P.un_mode && store_lane) {
                     double un0 = unsrc[c], un1 = unsrc[c + 1], un2 = unsrc[c + 2];
                     if (P.un_mode == 2) { un1 *= un0; un2 *= un0; } // u^n = p2c(p^n), cbdiso_2d.c:285-298
-                    u[0] = (1.0 - P.a) * u[0] + P.a * un0;
-                    u[1] = (1.0 - P.a) * u[1] + P.a * un1;
-                    u[2] = (1.0 - P.a) * u[2] + P.a * un2;
+                    const double b = 1.0 - P.a;
+                    u[0] = b * u[0] + P.a * un0;
+                    u[1] = b * u[1] + P.a * un1;
+                    u[2] = b * u[2] + P.a * un2;
                 }
                 // primitive recovery with floors (cbdiso_2d.c:268-283)
-                double rho = max2(u[0], P.dfloor);
-                double vx = copysign(1.0, u[1]) * min2(fabs(u[1] / rho), P.vmax);
-                double vy = copysign(1.0, u[2]) * min2(fabs(u[2] / rho), P.vmax);
+                double rho = __builtin_fmax(u[0], P.dfloor);
+                double rinv = fast_rcp(rho);
+                double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
+                double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
                 if (store_lane) {
                     pwr[c] = rho; pwr[c + 1] = vx; pwr[c + 2] = vy;
-                    if (P.want_wavespeed) {
-                        double c2 = iso_cs2(P, P.mw, xc, yc);
-                        amax = max2(amax, max_speed(vx, vy, c2));
+                    if (WS) {
+                        // max(|v-cs|,|v+cs|) == fl(|v| + cs) for cs >= 0, so the zone's speed is
+                        // fl(max(|vx|,|vy|) + cs).  A ~1-ulp estimate of cs filters the zones that
+                        // cannot raise this lane's running maximum; the rest take the IEEE path,
+                        // so the reduced value is bit-identical to cbdiso_2d_wavespeed + max.
+                        double vm = __builtin_fmax(fabs(vx), fabs(vy));
+                        double c2e, cse;
+                        iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
+                        if ((vm + cse) * (1.0 + 1e-9) >= amax) {
+#pragma clang fp contract(off)
+                            double c2 = iso_cs2(P, P.mw, xc, yc);
+                            amax = max2(amax, max_speed(vx, vy, c2));
+                        }
                     }
                 }
             }
@@ -281,7 +349,7 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
 #pragma unroll
         for (int q = 0; q < 3; ++q) { gyb[q] = gyc[q]; pa[q] = pb[q]; pb[q] = pc[q]; }
     }
-    if (P.want_wavespeed) {
+    if (WS) {
         amax = wave_max_nonneg(amax);
         if (lane == 0) atomic_max_nonneg(wmax, amax);
     }
@@ -334,7 +402,8 @@ __global__ void iso_mass_rate_kernel(IsoParams P, const double *__restrict__ pri
     double yc = P.yl + (j + 0.5) * P.dy;
     double p[3] = {prim[n], prim[n + 1], prim[n + 2]};
     double dc[3] = {rate[n], rate[n + 1], rate[n + 2]};
-    iso_mass_source(P.m[0], xc, yc, 1.0, p, dc);
+    double ddy = yc - P.m[0].y;
+    iso_mass_source(P.m[0], xc, ddy, ddy * ddy + P.m[0].rsoft * P.m[0].rsoft, 1.0, p, dc);
     rate[n] = dc[0]; rate[n + 1] = dc[1]; rate[n + 2] = dc[2];
 }
 

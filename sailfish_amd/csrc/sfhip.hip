@@ -92,7 +92,10 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = 4;
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    hipLaunchKernelGGL(sf::iso_stage_kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
+    if (P.want_wavespeed)
+        hipLaunchKernelGGL(sf::iso_stage_kernel<true>, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
+    else
+        hipLaunchKernelGGL(sf::iso_stage_kernel<false>, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
     return check_launch("cbdiso_2d stage launch");
 }
 
@@ -130,12 +133,21 @@ void fill_iso(sf::IsoParams &P, int ni, int nj, double pxl, double pxr, double p
     P.xl = pxl; P.yl = pyl;
     P.dx = (pxr - pxl) / ni; // cbdiso_2d.c:440-441
     P.dy = (pyr - pyl) / nj;
+    P.inv_dx = 1.0 / P.dx;
+    P.inv_dy = 1.0 / P.dy;
     P.m[0] = m1; P.m[1] = m2;
     P.buf_sd = bsd; P.buf_mc = bmc; P.buf_rate = brate; P.buf_rout = brout;
     P.buf_ron = brout - bw;                               // cbdiso_2d.c:229
     P.buf_omega = sqrt(bmc * pow(P.buf_ron, -3.0));       // cbdiso_2d.c:237 (host libm, as the reference)
+    P.buf_ron2 = P.buf_ron * P.buf_ron;
+    P.buf_rate_scale = brate * P.buf_omega / (brout - P.buf_ron); // cbdiso_2d.c:238
     P.buf_on = bon;
     P.eos = eos; P.cs2 = cs2; P.mach2 = mach2;
+    P.eos_local = eos == 2 && (m1.mass > 0.0 || m2.mass > 0.0);
+    // cbdiso_2d.c:194-211 for a spatially uniform sound speed (eos 2 without masses gives -0/M^2)
+    P.cs2_uniform = eos == 1 ? cs2 : (eos == 2 ? -0.0 / mach2 : 1.0);
+    P.cs_uniform = sqrt(P.cs2_uniform);
+    P.inv_mach2 = 1.0 / mach2;
     P.nu = nu; P.a = a; P.dt = dt; P.vmax = vmax; P.dfloor = dfloor;
     P.clamp_ilo = P.clamp_ihi = P.clamp_j = 0;
     P.un_mode = a != 0.0 ? 1 : 0;
@@ -188,6 +200,18 @@ __global__ void lane_shift_kernel(const double *in, double *out_below, double *o
     out_above[t] = sf::from_lane_above(x);
 }
 
+// fast-math self test: out[0..n) = fast_rcp(x), out[n..2n) = fast_rsqrt(x), out[2n..3n) = sqrt via rsqrt
+__global__ void fastmath_kernel(const double *x, double *out, int n)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double v = x[k];
+    double y = sf::fast_rsqrt(v);
+    out[k] = sf::fast_rcp(v);
+    out[n + k] = y;
+    out[2 * n + k] = sf::sqrt_from_rsqrt(v, y);
+}
+
 } // namespace
 
 extern "C" {
@@ -222,6 +246,13 @@ int sfhip_selftest_lane_shift(const double *in64, double *out_below64, double *o
 {
     hipLaunchKernelGGL(lane_shift_kernel, dim3(1), dim3(64), 0, t_stream, in64, out_below64, out_above64);
     return check_launch("lane_shift_kernel");
+}
+
+int sfhip_selftest_fastmath(int n, double *x, double *out3n)
+{
+    if (n < 1 || !x || !out3n) return fail(-1, "sfhip_selftest_fastmath: bad arguments");
+    hipLaunchKernelGGL(fastmath_kernel, dim3((n + 255) / 256), dim3(256), 0, t_stream, x, out3n, n);
+    return check_launch("fastmath_kernel");
 }
 
 // max over an array of non-negative doubles into *out (device); zeroes *out first

@@ -54,6 +54,19 @@ def test_lane_shift_selftest(hip_lib):
     assert np.array_equal(a[:-1], xh[1:]) and a[-1] == xh[-1]
 
 
+def test_fast_math_accuracy(hip_lib):
+    """fast_rcp / fast_rsqrt / sqrt_from_rsqrt (sf_device.hpp) stay within 2 ulp over 30 decades."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10.0 ** rng.uniform(-15, 15, 200000), rng.uniform(0.5, 2.0, 200000)])
+    n = x.size
+    out = dev(np.zeros(3 * n))
+    hip_lib.sfhip_selftest_fastmath[n](dev(x), out)
+    got = host(out).reshape(3, n)
+    for g, exact in zip(got, (1.0 / x, 1.0 / np.sqrt(x), np.sqrt(x))):
+        ulp = np.abs(g - exact) / np.spacing(np.abs(exact))
+        assert ulp.max() <= 2.0, ulp.max()
+
+
 @pytest.mark.parametrize("kw", cases.iso_branch_matrix(), ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
 def test_iso_advance_rk(hip_lib, orc, kw):
     c = cases.iso_case(seed=7, **kw)
