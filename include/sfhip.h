@@ -181,7 +181,11 @@ SFHIP_API int cbdiso_2d_wavespeed(
  * want_wavespeed (0 off, 1 accumulate into *wavespeed_max, 2 zero it first).
  * Only zone rows [i_begin, i_end) are updated (interior / boundary split while
  * halos are in flight).  The w* arguments are the point masses at the time the
- * output state belongs to. */
+ * output state belongs to.  wavespeed_floor is a filter, not a result: zones whose
+ * speed is below it are not folded in, so the reduced value is the exact global
+ * maximum whenever it comes out >= wavespeed_floor (after the cross-rank MAX); a
+ * caller that sees a smaller value recomputes with *_max_wavespeed.  Pass 0 to
+ * fold every zone. */
 SFHIP_API int sfhip_cbdiso_2d_stage(
     int ni,
     int nj,
@@ -230,6 +234,7 @@ SFHIP_API int sfhip_cbdiso_2d_stage(
     int i_begin, // :: 0 <= $ <= ni
     int i_end, // :: i_begin <= $ <= ni
     int want_wavespeed, // :: $ in [0, 1, 2]
+    double wavespeed_floor, // :: $ >= 0.0
     double wx1, // point masses at the output time
     double wy1,
     double wmass1,
@@ -420,6 +425,7 @@ SFHIP_API int sfhip_cbdgam_2d_stage(
     int i_begin, // :: 0 <= $ <= ni
     int i_end, // :: i_begin <= $ <= ni
     int want_wavespeed, // :: $ in [0, 1, 2]
+    double wavespeed_floor, // :: $ >= 0.0
     double *wavespeed_max) // :: $.numel() >= 1
 ;
 

@@ -31,6 +31,7 @@ struct GamParams {
     double alpha, a, dt, vmax, cooling, mach_ceiling_m2 /* pow(mach_ceiling,-2) */, dfloor, pfloor;
     int clamp_ilo, clamp_ihi, clamp_j, un_mode;
     int rows_per_chunk, i_begin, i_end, want_wavespeed;
+    double ws_floor; // accepted for symmetry with cbdiso; the gamma-law speed is cheap, every zone is folded
 };
 
 // sum_p m_p r_p^-3 with r^2 + 1e-12 (cbdgam_2d.c:85-101); returns < 0 when both masses are zero

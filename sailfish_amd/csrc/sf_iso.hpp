@@ -42,6 +42,7 @@ struct IsoParams {
     int rows_per_chunk;         // rows marched by one wave
     int i_begin, i_end;         // zone-row range [i_begin, i_end) to update (interior/boundary split for halo overlap)
     int want_wavespeed;         // fold max wavespeed of the OUTPUT state into *wmax
+    double ws_floor;            // zones slower than this are not folded in (see include/sfhip.h)
     Mass mw[2];                 // masses at the time the output state belongs to (for want_wavespeed)
 };
 
@@ -179,7 +180,7 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 // grid: 1-D, 256 threads = 4 waves; wave w of the grid owns column strip
 // (w % nstrips) and row chunk (w / nstrips).
 // ---------------------------------------------------------------------------
-template <bool WS>
+template <bool WS, bool UN>
 __global__ __launch_bounds__(256) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
@@ -231,12 +232,33 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
     double gyb[3] = {0, 0, 0};
     double pmx[3] = {1, 0, 0}, txx = 0, txy = 0;
     double Fp[3] = {0, 0, 0}, dGp[3] = {0, 0, 0};
-    double amax = 0.0;
+    double amax = 0.0;            // exact running maximum of this lane
+    double athr = P.ws_floor;     // what an estimate has to reach to be worth the exact evaluation
+
+    // software prefetch: row r+1 (and the u^n source of the row updated next) is requested one
+    // iteration ahead so its HBM latency overlaps this iteration's arithmetic
+    double pn[3], un[3] = {0, 0, 0}, unn[3] = {0, 0, 0};
+    {
+        int rl = I0 - 2 < rlo ? rlo : (I0 - 2 > rhi ? rhi : I0 - 2);
+        const double *src = prd + rl * si + col;
+        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
+    }
+    constexpr bool want_un = UN;
+    const long ucol = (long)(J < nj + 2 * NG ? J : nj + 2 * NG - 1) * sj;
 
     for (int r = I0 - 2; r <= I1 + 1; ++r) {
-        int rl = r < rlo ? rlo : (r > rhi ? rhi : r);
-        const double *src = prd + rl * si + col;
-        pc[0] = src[0]; pc[1] = src[1]; pc[2] = src[2];
+        pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2];
+        un[0] = unn[0]; un[1] = unn[1]; un[2] = unn[2];
+        if (r < I1 + 1) {
+            int rn = r + 1;
+            int rl = rn < rlo ? rlo : (rn > rhi ? rhi : rn);
+            const double *src = prd + rl * si + col;
+            pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
+            if (want_un && rn - 2 >= I0) {
+                const double *us = unsrc + (long)(rn - 2) * si + ucol;
+                unn[0] = us[0]; unn[1] = us[1]; unn[2] = us[2];
+            }
+        }
 
         // y-slopes of row r from the neighbouring lanes
         double gyc[3];
@@ -305,8 +327,8 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
                     u[q] += dc[q];
                 }
                 const long c = (long)(r - 2) * si + (long)J * sj;
-                if (P.un_mode && store_lane) {
-                    double un0 = unsrc[c], un1 = unsrc[c + 1], un2 = unsrc[c + 2];
+                if (want_un) {
+                    double un0 = un[0], un1 = un[1], un2 = un[2];
                     if (P.un_mode == 2) { un1 *= un0; un2 *= un0; } // u^n = p2c(p^n), cbdiso_2d.c:285-298
                     const double b = 1.0 - P.a;
                     u[0] = b * u[0] + P.a * un0;
@@ -328,10 +350,11 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
                         double vm = __builtin_fmax(fabs(vx), fabs(vy));
                         double c2e, cse;
                         iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
-                        if ((vm + cse) * (1.0 + 1e-9) >= amax) {
+                        if ((vm + cse) * (1.0 + 1e-9) >= athr) {
 #pragma clang fp contract(off)
                             double c2 = iso_cs2(P, P.mw, xc, yc);
                             amax = max2(amax, max_speed(vx, vy, c2));
+                            athr = max2(athr, amax);
                         }
                     }
                 }

@@ -92,10 +92,9 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = 4;
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    if (P.want_wavespeed)
-        hipLaunchKernelGGL(sf::iso_stage_kernel<true>, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
-    else
-        hipLaunchKernelGGL(sf::iso_stage_kernel<false>, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
+    auto kernel = P.want_wavespeed ? (P.un_mode ? sf::iso_stage_kernel<true, true> : sf::iso_stage_kernel<true, false>)
+                                   : (P.un_mode ? sf::iso_stage_kernel<false, true> : sf::iso_stage_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
     return check_launch("cbdiso_2d stage launch");
 }
 
@@ -306,6 +305,7 @@ int sfhip_cbdiso_2d_stage(
     double cs2, double mach_squared, int eos_type, double nu, double a, double dt,
     double velocity_ceiling, double density_floor,
     int un_mode, int clamp_ilo, int clamp_ihi, int i_begin, int i_end, int want_wavespeed,
+    double wavespeed_floor,
     double wx1, double wy1, double wmass1, double wsoftening_length1,
     double wx2, double wy2, double wmass2, double wsoftening_length2,
     double *wavespeed_max)
@@ -321,6 +321,7 @@ int sfhip_cbdiso_2d_stage(
     P.clamp_ilo = clamp_ilo; P.clamp_ihi = clamp_ihi; P.clamp_j = 1;
     P.i_begin = i_begin; P.i_end = i_end;
     P.want_wavespeed = want_wavespeed;
+    P.ws_floor = wavespeed_floor;
     P.mw[0] = make_mass(wx1, wy1, 0, 0, wmass1, wsoftening_length1, 0, 0, 0);
     P.mw[1] = make_mass(wx2, wy2, 0, 0, wmass2, wsoftening_length2, 0, 0, 0);
     return launch_iso_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
@@ -439,7 +440,7 @@ int sfhip_cbdgam_2d_stage(
     double alpha, double a, double dt, double velocity_ceiling, double cooling_coefficient,
     double mach_ceiling, double density_floor, double pressure_floor, int constant_softening,
     int un_mode, int clamp_ilo, int clamp_ihi, int i_begin, int i_end, int want_wavespeed,
-    double *wavespeed_max)
+    double wavespeed_floor, double *wavespeed_max)
 {
     sf::GamParams P;
     fill_gam(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, gamma_law_index,
@@ -453,6 +454,7 @@ int sfhip_cbdgam_2d_stage(
     P.clamp_ilo = clamp_ilo; P.clamp_ihi = clamp_ihi; P.clamp_j = 1;
     P.i_begin = i_begin; P.i_end = i_end;
     P.want_wavespeed = want_wavespeed;
+    P.ws_floor = wavespeed_floor;
     return launch_gam_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
 }
 

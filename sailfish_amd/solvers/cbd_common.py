@@ -265,6 +265,7 @@ class SolverBase:
             self.patches.append(patch)
         self._comm_stream = None
         self._mass_cache = (None, None)
+        self._wavespeed_floor = 0.0
         self.event_log = None  # bench.py sets this to a list to time every stage launch with HIP events
 
     def _patch_kwargs(self):
@@ -310,11 +311,25 @@ class SolverBase:
         Launch on every patch first, then one device->host read, then the
         cross-rank MAX.  After a fused step the per-patch maxima are already on
         the device (epilogue of the last stage) and no kernel runs at all.
+
+        The fused epilogue only folds zones at least half as fast as the
+        previous maximum (``wavespeed_floor``); its result is exact whenever it
+        is not below that floor, which is checked here on the global value.
         """
-        for p in self.patches:
-            if not (self.fused and p.wavespeed_valid):
+        floor = self._wavespeed_floor
+        have_fused = self.fused and all(p.wavespeed_valid for p in self.patches)
+        value = self._reduce_wavespeed(recompute=not have_fused)
+        if have_fused and value < floor:
+            value = self._reduce_wavespeed(recompute=True)
+        self._wavespeed_floor = 0.5 * value
+        return value
+
+    def _reduce_wavespeed(self, recompute):
+        if recompute:
+            for p in self.patches:
                 with p.execution_context:
                     p.launch_maximum_wavespeed(self.point_masses(p.time))
+                p.wavespeed_valid = True
         if len(self.patches) == 1:
             local = self.patches[0].wavespeed_max
         else:
@@ -383,14 +398,15 @@ class SolverBase:
 
     def _launch(self, p, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed):
         """One stage-kernel launch on patch `p`, optionally bracketed by HIP events on its stream."""
+        floor = self._wavespeed_floor
         if self.event_log is None:
-            p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed)
+            p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor)
             return
         torch = self._torch()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed)
+        p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor)
         e1.record()
         self.event_log.append(dict(zones=(i_end - i_begin) * p.shape[1], reads_un=un is not None, start=e0, stop=e1))
 
