@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""
+Generates the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes
+are data (inputs/expected outputs as .npz), committed so that the tests can run
+where the reference does not exist (the GPU box).
+
+What runs here is the reference itself:
+  * its Python classes, imported from /root/reference (setups, Kepler solver,
+    Physics, mesh, subdivide, Solver/Patch of cbdiso_2d and cbdgam_2d), and
+  * its C kernels, compiled in place from its own sources by
+    oracle/build_ref.py (plain gcc on KERNEL_LIB_HEADER + <solver>.c).
+The reference builds those kernels through cffi, which is only a build driver
+and is not installed in this image; `RefLibrary` below overrides the one method
+that would invoke it (Library.load_cpu_module, library.py:187-235) to load the
+gcc-built shared object instead.  Everything else -- parse_api, Kernel,
+KernelInvocation, to_ctypes, the solvers, set_bc, the RK schedule -- is the
+reference's code, unmodified.
+
+Fixtures:
+  kepler.npz            point masses at 50 times for (e, q) in {0, 0.3} x {1, 0.2}
+  iso_disk_64.npz       circumbinary-disk, isothermal, 64^2, 20 RK2 steps, 1 patch
+  iso_disk_128_p4.npz   same at 128^2 on 4 patches (== 1 patch bitwise)
+  iso_disk_rk3_48.npz   rk_order 3, 48^2, 3 patches (48/3 even split), 8 steps
+  iso_explosion_64.npz  cylindrical-explosion 64^2, 20 steps
+  gam_disk_64.npz       gamma-law disk 64^2, 20 steps (alpha viscosity, buffer)
+  gam_cooling_48.npz    gamma-law with cooling 1e-2, 48^2, 10 steps
+  gam_explosion_64.npz  gamma-law explosion 64^2, 20 steps
+Each solver fixture stores: initial primitive, final primitive, dt[], time[].
+"""
+import os
+import sys
+from ctypes import CDLL
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, ROOT)
+
+
+def reference_modules():
+    import subprocess
+
+    subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "build_ref.py")], check=True)
+
+    import sailfish.kernel.library as reflib
+    import sailfish.setups  # noqa: F401  (registers setup classes)
+    import sailfish.solvers.cbdgam_2d as ref_gam
+    import sailfish.solvers.cbdiso_2d as ref_iso
+    from sailfish.setup_base import SetupBase
+    from sailfish.solvers import make_solver
+
+    class RefLibrary(reflib.Library):
+        def load_cpu_module(self, code, name, mode="cpu", define_macros=dict()):
+            import numpy
+
+            solver = "cbdiso_2d" if "MODULE: cbdiso_2d" in code else "cbdgam_2d"
+            self.module = CDLL(os.path.join(ROOT, "oracle", "_ref", f"{solver}_{mode}.so"))
+            self.xp = numpy
+
+    ref_iso.Library = RefLibrary
+    ref_gam.Library = RefLibrary
+    return SetupBase, make_solver
+
+
+def run_reference(SetupBase, make_solver, setup_name, resolution, steps, model=None, options=None,
+                  num_patches=1, cfl=None):
+    setup = SetupBase.find_setup_class(setup_name)(**(model or {}))
+    mesh = setup.mesh(resolution)
+    solver = make_solver(setup.solver, setup.physics, options or {}, setup=setup, mesh=mesh,
+                         time=setup.start_time, solution=None, num_patches=num_patches, mode="cpu")
+    initial = solver.solution.copy()
+    cfl = cfl or solver.recommended_cfl
+    dts, times = [], []
+    for _ in range(steps):
+        # driver.py:508-512
+        dx = mesh.min_spacing(solver.time)
+        dt = dx / solver.maximum_wavespeed() * cfl
+        solver.advance(dt)
+        dts.append(dt)
+        times.append(solver.time)
+    return dict(initial=initial, final=solver.solution.copy(), dt=np.array(dts), time=np.array(times),
+                cfl=np.array(cfl), resolution=np.array(resolution), num_patches=np.array(num_patches))
+
+
+def kepler_fixture(SetupBase):
+    rows = []
+    times = np.concatenate([np.linspace(0.0, 13.0, 40), [0.1, 1e-3, 100.7, 6.283185307179586, 31.4, 1e3, 2.5, 7.7, 19.9, 50.0]])
+    for e in (0.0, 0.3):
+        for q in (1.0, 0.2):
+            setup = SetupBase.find_setup_class("circumbinary-disk")(eccentricity=e, mass_ratio=q)
+            for t in times:
+                m1, m2 = setup.point_masses(float(t))
+                for m in (m1, m2):
+                    rows.append([e, q, t, m.position_x, m.position_y, m.velocity_x, m.velocity_y, m.mass,
+                                 m.softening_length, m.sink_rate, m.sink_radius, m.sink_model.value])
+    return np.array(rows)
+
+
+def main():
+    SetupBase, make_solver = reference_modules()
+    run = lambda *a, **k: run_reference(SetupBase, make_solver, *a, **k)
+    out = {
+        "iso_disk_64": run("circumbinary-disk", 64, 20),
+        "iso_disk_128_p4": run("circumbinary-disk", 128, 20, num_patches=4),
+        "iso_disk_rk3_48": run("circumbinary-disk", 48, 8, options=dict(rk_order=3), num_patches=3),
+        "iso_explosion_64": run("cylindrical-explosion", 64, 20),
+        "gam_disk_64": run("circumbinary-disk", 64, 20, model=dict(eos="gamma-law")),
+        "gam_cooling_48": run("circumbinary-disk", 48, 10, model=dict(eos="gamma-law", cooling_coefficient=1e-2)),
+        "gam_explosion_64": run("cylindrical-explosion", 64, 20, model=dict(eos="gamma-law")),
+    }
+    for name, data in out.items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+        print(name, data["final"].shape, "t_end", data["time"][-1])
+    np.savez_compressed(os.path.join(HERE, "kepler.npz"), rows=kepler_fixture(SetupBase))
+    # one-patch == four-patch bitwise for the power-of-two mesh (recorded, then relied upon by tests)
+    one = run("circumbinary-disk", 128, 20, num_patches=1)
+    assert np.array_equal(one["final"], out["iso_disk_128_p4"]["final"])
+    print("128^2: 1 patch == 4 patches bitwise")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""
+Test infrastructure: a kernel backend for the Solver classes that runs on torch
+CPU tensors and evaluates every launch with the CPU oracle.  It lets the
+decomposition / halo-exchange / reduction logic of sailfish_amd.solvers run
+under multi-process gloo tests without a GPU.  It is injected through the
+solvers' ``backend=`` keyword; the package itself never imports it.
+
+The fused entry points have no oracle counterpart, so they are emulated from
+their specification in include/sfhip.h: index-clamp boundaries == reference
+set_bc copies, un_mode 2 == primitive_to_conserved of the source, row range,
+wavespeed folding with floor.
+"""
+import contextlib
+
+import numpy as np
+
+import oracle as _oracle
+from sailfish_amd.kernel.system import get_array_module
+
+NG = 2
+
+
+class _Invocation:
+    def __init__(self, lib, name, shape):
+        self.lib, self.name, self.shape = lib, name, tuple(shape)
+
+    def __call__(self, *args):
+        sym = _oracle.API[self.name]
+        names = [a.name for a in sym.args][len(self.shape):]
+        assert len(names) == len(args), (self.name, len(names), len(args))
+        kw = dict(zip(names, args))
+        getattr(self.lib, "_" + self.name)(self.shape, kw, list(args))
+
+
+class _Kernel:
+    def __init__(self, lib, name):
+        self.lib, self.name = lib, name
+
+    def __getitem__(self, shape):
+        if isinstance(shape, int):
+            shape = (shape,)
+        return _Invocation(self.lib, self.name, shape)
+
+
+def _np(t):
+    return None if t is None else t.numpy()
+
+
+class OracleLibrary:
+    def __init__(self):
+        self.orc = _oracle.oracle()
+
+    def __getattr__(self, name):
+        if name in _oracle.API:
+            return _Kernel(self, name)
+        raise AttributeError(name)
+
+    # -- helpers ----------------------------------------------------------
+    @staticmethod
+    def _clamped(rd, lo, hi):
+        p = rd.copy()
+        if lo:
+            p[:NG] = p[NG]
+        if hi:
+            p[-NG:] = p[-NG - 1]
+        p[:, :NG] = p[:, NG:NG + 1]
+        p[:, -NG:] = p[:, -NG - 1:-NG]
+        return p
+
+    def _fold(self, out_t, value, want):
+        if want == 2:
+            out_t.zero_()
+        out_t[0] = max(float(out_t[0]), value)
+
+    # -- cbdiso -------------------------------------------------------------
+    def _sfhip_cbdiso_2d_stage(self, shape, kw, args):
+        ni, nj = shape
+        rd = self._clamped(_np(kw["primitive_rd"]), kw["clamp_ilo"], kw["clamp_ihi"])
+        cons = np.zeros_like(rd)
+        if kw["a"] != 0.0 and kw["un_mode"] == 2:
+            self.orc.call("cbdiso_2d_primitive_to_conserved", shape, _np(kw["un_source"]).copy(), cons)
+        elif kw["a"] != 0.0 and kw["un_mode"] == 1:
+            cons = _np(kw["un_source"]).copy()
+        out = np.zeros_like(rd)
+        ref_args = list(args[:41 - 2])  # the 39 arguments after (ni, nj) shared with cbdiso_2d_advance_rk
+        ref_args[4], ref_args[5], ref_args[6] = cons, rd, out
+        self.orc.call("cbdiso_2d_advance_rk", shape, *ref_args)
+        i0, i1 = kw["i_begin"] + NG, kw["i_end"] + NG
+        _np(kw["primitive_wr"])[i0:i1, NG:-NG] = out[i0:i1, NG:-NG]
+        if kw["want_wavespeed"]:
+            ws = np.zeros(rd.shape[:2])
+            self.orc.call(
+                "cbdiso_2d_wavespeed", shape, *args[0:4], kw["cs2"], kw["mach_squared"], kw["eos_type"],
+                kw["wx1"], kw["wy1"], 0.0, 0.0, kw["wmass1"], kw["wsoftening_length1"], 0.0, 0.0, 0,
+                kw["wx2"], kw["wy2"], 0.0, 0.0, kw["wmass2"], kw["wsoftening_length2"], 0.0, 0.0, 0, out, ws)
+            sel = ws[i0:i1, NG:-NG]
+            sel = sel[sel >= kw["wavespeed_floor"]]
+            self._fold(kw["wavespeed_max"], float(sel.max()) if sel.size else 0.0, kw["want_wavespeed"])
+
+    def _sfhip_cbdiso_2d_max_wavespeed(self, shape, kw, args):
+        prim = _np(kw["primitive"])
+        ws = np.zeros(prim.shape[:2])
+        self.orc.call(
+            "cbdiso_2d_wavespeed", shape, *args[0:7],
+            kw["x1"], kw["y1"], 0.0, 0.0, kw["mass1"], kw["softening_length1"], 0.0, 0.0, 0,
+            kw["x2"], kw["y2"], 0.0, 0.0, kw["mass2"], kw["softening_length2"], 0.0, 0.0, 0, prim, ws)
+        self._fold(kw["wavespeed_max"], float(ws.max()), 2)
+
+    # -- cbdgam -------------------------------------------------------------
+    def _sfhip_cbdgam_2d_stage(self, shape, kw, args):
+        rd = self._clamped(_np(kw["primitive_rd"]), kw["clamp_ilo"], kw["clamp_ihi"])
+        g = kw["gamma_law_index"]
+        cons = np.zeros_like(rd)
+        if kw["a"] != 0.0 and kw["un_mode"] == 2:
+            self.orc.call("cbdgam_2d_primitive_to_conserved", shape, _np(kw["un_source"]).copy(), cons, g)
+        elif kw["a"] != 0.0 and kw["un_mode"] == 1:
+            cons = _np(kw["un_source"]).copy()
+        out = np.zeros_like(rd)
+        ref_args = list(args[:44 - 2])
+        ref_args[4], ref_args[5], ref_args[6] = cons, rd, out
+        self.orc.call("cbdgam_2d_advance_rk", shape, *ref_args)
+        i0, i1 = kw["i_begin"] + NG, kw["i_end"] + NG
+        _np(kw["primitive_wr"])[i0:i1, NG:-NG] = out[i0:i1, NG:-NG]
+        if kw["want_wavespeed"]:
+            ws = np.zeros(rd.shape[:2])
+            self.orc.call("cbdgam_2d_wavespeed", shape, out, ws, g)
+            self._fold(kw["wavespeed_max"], float(ws[i0:i1, NG:-NG].max()), kw["want_wavespeed"])
+
+    def _sfhip_cbdgam_2d_max_wavespeed(self, shape, kw, args):
+        prim = _np(kw["primitive"])
+        ws = np.zeros(prim.shape[:2])
+        self.orc.call("cbdgam_2d_wavespeed", shape, prim, ws, kw["gamma_law_index"])
+        self._fold(kw["wavespeed_max"], float(ws.max()), 2)
+
+
+class OracleBackend:
+    mode = "host"
+
+    def __init__(self):
+        self.lib = OracleLibrary()
+        self.xp = get_array_module("host")
+
+    def context(self, device_id):
+        return contextlib.nullcontext()
+
+    def num_devices(self):
+        return 1
