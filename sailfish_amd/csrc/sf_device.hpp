@@ -65,6 +65,21 @@ __device__ __forceinline__ double plm(double yl, double y0, double yr)
     return same ? copysign(m, d1) : 0.0;
 }
 
+// TWICE the slope above, exactly (all scalings are powers of two): saves the
+// multiply by 0.5; callers reconstruct with p +- 0.25 * plm2.  When d1 and d2
+// agree in sign, yr - yl has that sign too (yl <= y0 <= yr or the reverse, and
+// comparisons are exact), so only two sign bits need testing.
+template <int THETA10>
+__device__ __forceinline__ double plm2(double yl, double y0, double yr)
+{
+    constexpr double theta2 = 2.0 * (THETA10 / 10.0);
+    double d1 = y0 - yl;
+    double d2 = yr - y0;
+    double m = __builtin_fmin(__builtin_fmin(fabs(d1), fabs(d2)) * theta2, fabs(yr - yl));
+    bool same = (__double2hiint(d1) ^ __double2hiint(d2)) >= 0;
+    return same ? copysign(m, d1) : 0.0;
+}
+
 // ---------------------------------------------------------------------------
 // Fast fp64 reciprocal / reciprocal square root.  IEEE fp64 division and sqrt
 // expand to ~11-12 VALU instructions each on CDNA; the stage kernels are

@@ -181,7 +181,7 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 // (w % nstrips) and row chunk (w / nstrips).
 // ---------------------------------------------------------------------------
 template <bool WS, bool UN>
-__global__ __launch_bounds__(256) void iso_stage_kernel(
+__global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
         cyw1 = (yc - P.mw[1].y) * (yc - P.mw[1].y) + P.mw[1].rsoft * P.mw[1].rsoft;
     }
     const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
+    const double hidx = 0.5 * P.inv_dx, hidy = 0.5 * P.inv_dy; // slopes are carried doubled
 
     double pa[3] = {1, 0, 0}, pb[3] = {1, 0, 0}, pc[3];
     double gyb[3] = {0, 0, 0};
@@ -264,19 +265,19 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
         double gyc[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            gyc[q] = plm<18>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]));
+            gyc[q] = plm2<18>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q])); // 2 x slope
 
         if (r >= I0) {
             // row r-1 now has both neighbours: x-slopes and strain (cbdiso_2d.c:248-263)
             double gxb[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gxb[q] = plm<18>(pa[q], pb[q], pc[q]);
+            for (int q = 0; q < 3; ++q) gxb[q] = plm2<18>(pa[q], pb[q], pc[q]); // 2 x slope
             double sxx = 0, syy = 0, sxy = 0;
             if (visc) {
-                double ax = gxb[1] * P.inv_dx, by = gyb[2] * P.inv_dy;
+                double ax = gxb[1] * hidx, by = gyb[2] * hidy;
                 sxx = c43 * ax - c23 * by;
                 syy = c43 * by - c23 * ax;
-                sxy = gxb[2] * P.inv_dx + gyb[1] * P.inv_dy;
+                sxy = gxb[2] * hidx + gyb[1] * hidy;
             }
 
             double F[3] = {0, 0, 0}, dG[3] = {0, 0, 0};
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
                 // x-face between rows r-2 and r-1 (cbdiso_2d.c:536-541, 560-561, 579-582)
                 double ppx[3], c2, cs;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - 0.5 * gxb[q];
+                for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - 0.25 * gxb[q];
                 iso_sound_fast(P, P.m, xf, cyc0, cyc1, c2, cs);
                 iso_hlle<0>(pmx, ppx, c2, cs, F);
                 if (visc) {
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
                 double pmy[3], ppy[3], G[3], c2, cs;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    pmy[q] = from_lane_below(pb[q] + 0.5 * gyb[q]);
-                    ppy[q] = pb[q] - 0.5 * gyb[q];
+                    pmy[q] = from_lane_below(pb[q] + 0.25 * gyb[q]);
+                    ppy[q] = pb[q] - 0.25 * gyb[q];
                 }
                 iso_sound_fast(P, P.m, xcb, cyf0, cyf1, c2, cs);
                 iso_hlle<1>(pmy, ppy, c2, cs, G);
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void iso_stage_kernel(
             // slide the window: row r-1 becomes the lower side of the next x-face
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                pmx[q] = pb[q] + 0.5 * gxb[q];
+                pmx[q] = pb[q] + 0.25 * gxb[q];
                 Fp[q] = F[q];
                 dGp[q] = dG[q];
             }
