@@ -33,9 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_STAGE_NO_UN = 48.0  # read p, write p' (3 fp64 each)            SURVEY.md 8(d)
-BYTES_STAGE_UN = 72.0     # + read u^n source at the zone centre      SURVEY.md 8(d)
-BYTES_PER_ZONE_UPDATE = 120.0
+# Algorithmic bytes per zone: a stage reads p and writes p' (NCONS fp64 each); a stage
+# with a != 0 also reads the u^n source at the zone centre.  RK2 zone-update = one of each.
+NCONS = {"iso": 3, "gam": 4}
 
 
 def parse_args():
@@ -154,6 +154,9 @@ def main():
 
     zones = mesh.num_total_zones
     mzps = zones * args.steps / seconds * 1e-6
+    BYTES_STAGE_NO_UN = 2 * 8.0 * NCONS[args.solver]
+    BYTES_STAGE_UN = 3 * 8.0 * NCONS[args.solver]
+    BYTES_PER_ZONE_UPDATE = BYTES_STAGE_NO_UN + BYTES_STAGE_UN
 
     roofline = None
     kernel_ms = None
@@ -196,7 +199,7 @@ def main():
             cpu = dict(value=None, unit="Mzps", cores=0, kind="port", sample=f"failed: {exc!r}")
 
     if rank == 0:
-        bytes_per_update = BYTES_PER_ZONE_UPDATE if args.solver == "iso" else 160.0
+        bytes_per_update = BYTES_PER_ZONE_UPDATE
         line = {
             "metric": "zone-updates/sec (Mzps) fp64, cbdiso_2d" if args.solver == "iso" else "zone-updates/sec (Mzps) fp64, cbdgam_2d",
             "value": round(mzps, 2),

@@ -22,17 +22,22 @@ namespace sf {
 
 struct GamParams {
     int ni, nj;
-    double xl, yl, dx, dy;
+    double xl, yl, dx, dy, inv_dx, inv_dy;
     Mass m[2];
-    double gamma;
+    double gamma, gm1, inv_gm1, sqrt_gamma;      // gamma-1, 1/(gamma-1), sqrt(gamma) from the host
     double buf_sd, buf_sp, buf_mc, buf_rate, buf_rout, buf_ron, buf_omega;
+    double buf_ron2, buf_rate_scale, buf_e0;     // ron^2, rate*omega/(rout-ron), surface_pressure/(gamma-1)
     int buf_on;
     int constant_softening;
+    int any_mass;                                // some mass != 0: disk_height is not the constant 1
     double alpha, a, dt, vmax, cooling, mach_ceiling_m2 /* pow(mach_ceiling,-2) */, dfloor, pfloor;
+    double mach_floor_scale;                     // 2/gamma/(gamma-1)*mach_ceiling^-2, cbdgam_2d.c:314
     int clamp_ilo, clamp_ihi, clamp_j, un_mode;
     int rows_per_chunk, i_begin, i_end, want_wavespeed;
-    double ws_floor; // accepted for symmetry with cbdiso; the gamma-law speed is cheap, every zone is folded
+    double ws_floor; // zones slower than this are not folded in (see include/sfhip.h)
 };
+
+// ---- exact pieces (reference-named small kernels, wavespeed/dt path) -------
 
 // sum_p m_p r_p^-3 with r^2 + 1e-12 (cbdgam_2d.c:85-101); returns < 0 when both masses are zero
 __device__ __forceinline__ double gam_omega2(const Mass *m, double x, double y)
@@ -66,38 +71,7 @@ __device__ __forceinline__ void gam_p2c(const double *p, double *u, double gamma
     u[3] = p[3] / (gamma - 1.0) + 0.5 * p[0] * (p[1] * p[1] + p[2] * p[2]);
 }
 
-// Two HLLE fluxes through one face (see header comment).  cbdgam_2d.c:374-434.
-template <int DIR>
-__device__ __forceinline__ void gam_hlle2(const double *pm, const double *pp, double cs2L, double cs2R,
-                                          double gamma, double *fR, double *fL)
-{
-    double ul[4], ur[4], fl[4], fr[4];
-    gam_p2c(pm, ul, gamma);
-    gam_p2c(pp, ur, gamma);
-    double vl = pm[1 + DIR], vr = pp[1 + DIR];
-    fl[0] = vl * ul[0]; fl[1] = vl * ul[1]; fl[2] = vl * ul[2]; fl[3] = vl * (ul[3] + pm[3]);
-    fr[0] = vr * ur[0]; fr[1] = vr * ur[1]; fr[2] = vr * ur[2]; fr[3] = vr * (ur[3] + pp[3]);
-    fl[1 + DIR] += pm[3];
-    fr[1 + DIR] += pp[3];
-    {
-        double cs = sqrt(cs2L);
-        double am = min2(0.0, min2(vl - cs, vr - cs));
-        double ap = max2(0.0, max2(vl + cs, vr + cs));
-        double den = ap - am;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fR[q] = (fl[q] * ap - fr[q] * am - (ul[q] - ur[q]) * ap * am) / den;
-    }
-    {
-        double cs = sqrt(cs2R);
-        double am = min2(0.0, min2(vl - cs, vr - cs));
-        double ap = max2(0.0, max2(vl + cs, vr + cs));
-        double den = ap - am;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fL[q] = (fl[q] * ap - fr[q] * am - (ul[q] - ur[q]) * ap * am) / den;
-    }
-}
-
-// One point mass, cbdgam_2d.c:108-203.  Adds its contribution to u.
+// One point mass, cbdgam_2d.c:108-203, IEEE arithmetic (diagnostics kernel).  Adds its contribution to u.
 __device__ __forceinline__ void gam_mass_source(const Mass &m, double x1, double y1, double dt, const double *prim,
                                                 double h, double *u, int constant_softening, double gamma)
 {
@@ -154,45 +128,159 @@ __device__ __forceinline__ void gam_mass_source(const Mass &m, double x1, double
     }
 }
 
-// cbdgam_2d.c:238-276
-__device__ __forceinline__ void gam_buffer(const GamParams &P, double xc, double yc, double *u)
+// ---- fast pieces: the stage kernel (fast_rcp / fast_rsqrt, FMA contraction) -
+
+// 1/sqrt(sum_p m_p r_p^-3) at a point; c0, c1 = (y - y_p)^2 + 1e-12 precomputed per lane.
+// Multiplying sqrt(p/sigma) by it gives disk_height (cbdgam_2d.c:75-106).
+__device__ __forceinline__ double gam_inv_omega_fast(const Mass *m, double x, double c0, double c1)
 {
-    if (!P.buf_on) return;
-    double rc = sqrt(xc * xc + yc * yc);
-    if (rc > P.buf_ron) {
-        double pf = P.buf_sd * sqrt(P.buf_mc / rc);
-        double px = pf * (-yc / rc);
-        double py = pf * (xc / rc);
-        double ke = 0.5 * (px * px + py * py) / P.buf_sd;
-        double en = P.buf_sp / (P.gamma - 1.0) + ke;
-        double u0[4] = {P.buf_sd, px, py, en};
-        double br = P.buf_rate * P.buf_omega * (rc - P.buf_ron) / (P.buf_rout - P.buf_ron);
+#pragma clang fp contract(fast)
+    double om2 = 0.0;
+    if (m[0].mass > 0.0) { double d = x - m[0].x; double y = fast_rsqrt(d * d + c0); om2 += m[0].mass * (y * y * y); }
+    if (m[1].mass > 0.0) { double d = x - m[1].x; double y = fast_rsqrt(d * d + c1); om2 += m[1].mass * (y * y * y); }
+    return fast_rsqrt(om2);
+}
+
+// Two HLLE fluxes through one face (see header comment), cbdgam_2d.c:374-434;
+// csL / csR are the sound speeds of the zones below / above the face.
+template <int DIR>
+__device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *pp, double csL, double csR,
+                                               double inv_gm1, double *fR, double *fL)
+{
+#pragma clang fp contract(fast)
+    double ul[4], ur[4], fl[4], fr[4], du[4];
+    ul[0] = pm[0]; ul[1] = pm[1] * pm[0]; ul[2] = pm[2] * pm[0];
+    ul[3] = pm[3] * inv_gm1 + 0.5 * pm[0] * (pm[1] * pm[1] + pm[2] * pm[2]);
+    ur[0] = pp[0]; ur[1] = pp[1] * pp[0]; ur[2] = pp[2] * pp[0];
+    ur[3] = pp[3] * inv_gm1 + 0.5 * pp[0] * (pp[1] * pp[1] + pp[2] * pp[2]);
+    double vl = pm[1 + DIR], vr = pp[1 + DIR];
+    fl[0] = vl * ul[0]; fl[1] = vl * ul[1]; fl[2] = vl * ul[2]; fl[3] = vl * (ul[3] + pm[3]);
+    fr[0] = vr * ur[0]; fr[1] = vr * ur[1]; fr[2] = vr * ur[2]; fr[3] = vr * (ur[3] + pp[3]);
+    fl[1 + DIR] += pm[3];
+    fr[1 + DIR] += pp[3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[q] -= (u[q] - u0[q]) * br * P.dt;
+    for (int q = 0; q < 4; ++q) du[q] = ul[q] - ur[q];
+    {
+        double am = __builtin_fmin(0.0, __builtin_fmin(vl - csL, vr - csL));
+        double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csL, vr + csL));
+        double rden = fast_rcp(ap - am), apam = ap * am;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fR[q] = (fl[q] * ap - fr[q] * am - du[q] * apam) * rden;
+    }
+    {
+        double am = __builtin_fmin(0.0, __builtin_fmin(vl - csR, vr - csR));
+        double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csR, vr + csR));
+        double rden = fast_rcp(ap - am), apam = ap * am;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fL[q] = (fl[q] * ap - fr[q] * am - du[q] * apam) * rden;
+    }
+}
+
+// One point mass, cbdgam_2d.c:108-203.  `ddy`, `cy` = ddy^2 (+ rs^2 when softening is constant) per lane;
+// `eps` = specific internal energy, `h` = disk height (non-constant softening only).
+__device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double x1, double ddy, double dt,
+                                                     const double *prim, double eps, double h, double *u,
+                                                     int constant_softening)
+{
+#pragma clang fp contract(fast)
+    if (m.sink_model < 1 || m.sink_model > 3) return; // inactive: no gravity either (cbdgam_2d.c:194-201)
+    double sigma = prim[0];
+    double ddx = x1 - m.x;
+    double r2 = ddx * ddx + ddy * ddy;
+    double r_sink = m.sink_radius;
+    double rs4 = 4.0 * r_sink;
+    double r_soft = m.rsoft;
+    double rate = 0.0;
+    double dr = 0.0;
+    const bool near = r2 < rs4 * rs4;
+    if (!constant_softening || near) dr = sqrt(r2);
+    if (!constant_softening) {
+        if (dr > r_sink) r_soft = 0.5 * h;
+        else {
+            double q = dr / r_sink;
+            double t = 1.0 - q * q;
+            double tr = t * t;
+            r_soft = tr * r_sink + (1.0 - tr) * 0.5 * h;
+        }
+    }
+    if (near && dr < rs4) {
+        double q = dr / r_sink;
+        double q2 = q * q;
+        rate = m.sink_rate * exp(-(q2 * q2));
+    }
+    double y = fast_rsqrt(r2 + r_soft * r_soft);
+    double fnum = sigma * m.mass * (y * y * y);
+    double fx = -fnum * ddx;
+    double fy = -fnum * ddy;
+    double vx = prim[1], vy = prim[2];
+    double work = dt * (fx * vx + fy * vy);
+    u[1] += dt * fx;
+    u[2] += dt * fy;
+    u[3] += work;
+    if (rate != 0.0) {
+        double mdot = -(sigma * rate);
+        u[0] += dt * mdot;
+        if (m.sink_model == 1) {
+            u[1] += dt * mdot * vx;
+            u[2] += dt * mdot * vy;
+            u[3] += dt * (mdot * eps + 0.5 * mdot * (vx * vx + vy * vy));
+        } else if (m.sink_model == 2) {
+            double rinv = 1.0 / (dr + 1e-12);
+            double rhx = ddx * rinv, rhy = ddy * rinv;
+            double dv = (vx - m.vx) * rhx + (vy - m.vy) * rhy;
+            double vxs = dv * rhx + m.vx;
+            double vys = dv * rhy + m.vy;
+            u[1] += dt * mdot * vxs;
+            u[2] += dt * mdot * vys;
+            u[3] += dt * (mdot * eps + 0.5 * mdot * (vxs * vxs + vys * vys));
+        }
+    }
+}
+
+// cbdgam_2d.c:238-276
+__device__ __forceinline__ void gam_buffer_fast(const GamParams &P, double xc, double yc, double yc2, double *u)
+{
+#pragma clang fp contract(fast)
+    if (!P.buf_on) return;
+    double rc2 = xc * xc + yc2;
+    if (rc2 > P.buf_ron2) {
+        double rinv = fast_rsqrt(rc2);
+        double rc = sqrt_from_rsqrt(rc2, rinv);
+        double vk2 = P.buf_mc * rinv;
+        double pf = P.buf_sd * sqrt_from_rsqrt(vk2, fast_rsqrt(vk2)) * rinv; // sigma v_kep / rc
+        double px = -pf * yc, py = pf * xc;
+        double en = P.buf_e0 + 0.5 * (px * px + py * py) * fast_rcp(P.buf_sd);
+        double br = P.buf_rate_scale * (rc - P.buf_ron) * P.dt;
+        u[0] -= (u[0] - P.buf_sd) * br;
+        u[1] -= (u[1] - px) * br;
+        u[2] -= (u[2] - py) * br;
+        u[3] -= (u[3] - en) * br;
     }
 }
 
 // cbdgam_2d.c:298-317
-__device__ __forceinline__ void gam_cooling(const GamParams &P, const double *prim, double *u)
+__device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const double *prim, double eps, double rinv_sigma,
+                                                 double *u)
 {
-    double gamma = P.gamma;
+#pragma clang fp contract(fast)
     double sigma = prim[0];
-    double eps = prim[3] / prim[0] / (gamma - 1.0);
     double ec = eps;
     if (P.cooling != 0.0) {
-        double arg = 1.0 + 3.0 * P.cooling * (1.0 / (sigma * sigma)) * (eps * eps * eps) * P.dt;
-        ec = eps * pow(arg, -1.0 / 3.0);
+        double arg = 1.0 + 3.0 * P.cooling * (rinv_sigma * rinv_sigma) * (eps * eps * eps) * P.dt;
+        ec = eps * rcbrt(arg);
     }
     double vx = prim[1], vy = prim[2];
     double ek = 0.5 * (vx * vx + vy * vy);
-    ec = max2(ec, 2.0 * ek / gamma / (gamma - 1.0) * P.mach_ceiling_m2);
+    ec = __builtin_fmax(ec, ek * P.mach_floor_scale);
     u[3] += sigma * (ec - eps);
 }
 
+template <bool WS, bool UN>
 __global__ __launch_bounds__(256) void gam_stage_kernel(
     GamParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
+#pragma clang fp contract(fast)
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int strip = gw % nstrips;
@@ -203,12 +291,14 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
     const long sj = 4, si = 4L * (nj + 2 * NG);
     const double gamma = P.gamma;
     const bool visc = P.alpha > 0.0;
+    const bool hvar = P.any_mass != 0; // disk height varies in space
 
     const int J = strip * STRIP + lane;
     int Jld = J;
     if (P.clamp_j) Jld = Jld < NG ? NG : (Jld > nj + NG - 1 ? nj + NG - 1 : Jld);
     else           Jld = Jld > nj + 2 * NG - 1 ? nj + 2 * NG - 1 : Jld;
     const long col = Jld * sj;
+    const long ucol = (long)(J < nj + 2 * NG ? J : nj + 2 * NG - 1) * sj;
     const bool store_lane = lane >= HALO && lane < WAVE - HALO && J < nj + NG;
     const int jz = J - NG;
     const double yc = P.yl + (jz + 0.5) * P.dy;
@@ -220,40 +310,68 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
     const int rlo = P.clamp_ilo ? NG : 0;
     const int rhi = P.clamp_ihi ? ni + NG - 1 : ni + 2 * NG - 1;
 
-    double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4];
+    // lane-invariant pieces of the distances to the masses
+    const double dyc0 = yc - P.m[0].y, dyc1 = yc - P.m[1].y;
+    const double oyc0 = dyc0 * dyc0 + 1e-12, oyc1 = dyc1 * dyc1 + 1e-12;                       // omega at centres / x-faces
+    const double oyf0 = (yf - P.m[0].y) * (yf - P.m[0].y) + 1e-12, oyf1 = (yf - P.m[1].y) * (yf - P.m[1].y) + 1e-12;
+    const double yc2 = yc * yc;
+    const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
+    const double hidx = 0.5 * P.inv_dx, hidy = 0.5 * P.inv_dy; // slopes are carried doubled
+
+    double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4], pn[4], un[4] = {0, 0, 0, 0}, unn[4] = {0, 0, 0, 0};
     double gyb[4] = {0, 0, 0, 0};
     // carried from row r-2 (the lower side of the next x-face)
-    double pmx[4] = {1, 0, 0, 1}, sxxa = 0, sxya = 0, c2a = 1, qha = 1, nua = 0;
+    double pmx[4] = {1, 0, 0, 1}, sxxa = 0, sxya = 0, csa = 1, qha = 1, nua = 0;
     double Fp[4] = {0, 0, 0, 0};  // lower-face flux of row r-2 as that row sees it
     double dGp[4] = {0, 0, 0, 0}; // (upper - lower) y-flux difference of row r-2
-    double amax = 0.0;
+    double amax = 0.0, athr = P.ws_floor;
+
+    {
+        int rl = I0 - 2 < rlo ? rlo : (I0 - 2 > rhi ? rhi : I0 - 2);
+        const double *src = prd + rl * si + col;
+        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+    }
 
     for (int r = I0 - 2; r <= I1 + 1; ++r) {
-        int rl = r < rlo ? rlo : (r > rhi ? rhi : r);
-        const double *src = prd + rl * si + col;
-        pc[0] = src[0]; pc[1] = src[1]; pc[2] = src[2]; pc[3] = src[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pc[q] = pn[q]; un[q] = unn[q]; }
+        if (r < I1 + 1) {
+            int rn = r + 1;
+            int rl = rn < rlo ? rlo : (rn > rhi ? rhi : rn);
+            const double *src = prd + rl * si + col;
+            pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+            if (UN && rn - 2 >= I0) {
+                const double *us = unsrc + (long)(rn - 2) * si + ucol;
+                unn[0] = us[0]; unn[1] = us[1]; unn[2] = us[2]; unn[3] = us[3];
+            }
+        }
 
         double gyc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            gyc[q] = plm<15>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]));
+            gyc[q] = plm2<15>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q])); // 2 x slope
 
         if (r >= I0) {
             double gxb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gxb[q] = plm<15>(pa[q], pb[q], pc[q]);
-            double sxx = 4.0 / 3.0 * gxb[1] / P.dx - 2.0 / 3.0 * gyb[2] / P.dy;
-            double syy = -2.0 / 3.0 * gxb[1] / P.dx + 4.0 / 3.0 * gyb[2] / P.dy;
-            double sxy = gxb[2] / P.dx + gyb[1] / P.dy;
+            for (int q = 0; q < 4; ++q) gxb[q] = plm2<15>(pa[q], pb[q], pc[q]); // 2 x slope
+            double sxx = 0, syy = 0, sxy = 0;
+            if (visc) {
+                double ax = gxb[1] * hidx, by = gyb[2] * hidy;
+                sxx = c43 * ax - c23 * by;
+                syy = c43 * by - c23 * ax;
+                sxy = gxb[2] * hidx + gyb[1] * hidy;
+            }
 
             const double xf = P.xl + (double)(r - 1 - NG) * P.dx;
             const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;
-            const double c2b = pb[3] / pb[0] * gamma;              // cbdgam_2d.c:231-236
-            double qhb = 0, nub = 0;
-            if (visc) {
-                qhb = sqrt(pb[3] / pb[0]);
-                nub = P.alpha * gam_height(qhb, gam_omega2(P.m, xcb, yc)) * sqrt(c2b); // cbdgam_2d.c:644
-            }
+            // sqrt(p/sigma) and sound speed of row r-1 (cbdgam_2d.c:231-236): cs = sqrt(gamma p/sigma)
+            const double prb = pb[3] * fast_rcp(pb[0]);
+            const double qhb = sqrt_from_rsqrt(prb, fast_rsqrt(prb));
+            const double csb = qhb * P.sqrt_gamma;
+            double nub = 0;
+            if (visc) // nu = alpha h cs at the zone centre, cbdgam_2d.c:644
+                nub = P.alpha * (hvar ? qhb * gam_inv_omega_fast(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
 
             double FR[4] = {0, 0, 0, 0}, FL[4] = {0, 0, 0, 0}, dG[4] = {0, 0, 0, 0};
 
@@ -261,20 +379,20 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                 // x-face between rows r-2 (L) and r-1 (R)
                 double ppx[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ppx[q] = pb[q] - 0.5 * gxb[q];
-                gam_hlle2<0>(pmx, ppx, c2a, c2b, gamma, FR, FL);
+                for (int q = 0; q < 4; ++q) ppx[q] = pb[q] - 0.25 * gxb[q];
+                gam_hlle2_fast<0>(pmx, ppx, csa, csb, P.inv_gm1, FR, FL);
                 if (visc) {
-                    double om2f = gam_omega2(P.m, xf, yc);
-                    double nufL = P.alpha * gam_height(qha, om2f) * sqrt(c2a); // cbdgam_2d.c:639,645
-                    double nufR = P.alpha * gam_height(qhb, om2f) * sqrt(c2b); // cbdgam_2d.c:640,646
-                    FR[1] -= 0.5 * (nufL * pa[0] * sxxa + nub * pb[0] * sxx);
-                    FR[2] -= 0.5 * (nufL * pa[0] * sxya + nub * pb[0] * sxy);
-                    FR[3] -= 0.5 * (nufL * pa[0] * sxxa * pa[1] + nub * pb[0] * sxx * pb[1]);
-                    FR[3] -= 0.5 * (nufL * pa[0] * sxya * pa[2] + nub * pb[0] * sxy * pb[2]);
-                    FL[1] -= 0.5 * (nua * pa[0] * sxxa + nufR * pb[0] * sxx);
-                    FL[2] -= 0.5 * (nua * pa[0] * sxya + nufR * pb[0] * sxy);
-                    FL[3] -= 0.5 * (nua * pa[0] * sxxa * pa[1] + nufR * pb[0] * sxx * pb[1]);
-                    FL[3] -= 0.5 * (nua * pa[0] * sxya * pa[2] + nufR * pb[0] * sxy * pb[2]);
+                    double iof = hvar ? gam_inv_omega_fast(P.m, xf, oyc0, oyc1) : 1.0;
+                    double nufL = P.alpha * (hvar ? qha * iof : 1.0) * csa; // cbdgam_2d.c:639,645
+                    double nufR = P.alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:640,646
+                    double txa = pa[0] * sxxa, tya = pa[0] * sxya, txb = pb[0] * sxx, tyb = pb[0] * sxy;
+                    double exa = txa * pa[1] + tya * pa[2], exb = txb * pb[1] + tyb * pb[2];
+                    FR[1] -= 0.5 * (nufL * txa + nub * txb);
+                    FR[2] -= 0.5 * (nufL * tya + nub * tyb);
+                    FR[3] -= 0.5 * (nufL * exa + nub * exb);
+                    FL[1] -= 0.5 * (nua * txa + nufR * txb);
+                    FL[2] -= 0.5 * (nua * tya + nufR * tyb);
+                    FL[3] -= 0.5 * (nua * exa + nufR * exb);
                 }
             }
             if (r - 1 >= I0 && r - 1 < I1) {
@@ -282,30 +400,26 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                 double pmy[4], ppy[4], GR[4], GL[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pmy[q] = from_lane_below(pb[q] + 0.5 * gyb[q]);
-                    ppy[q] = pb[q] - 0.5 * gyb[q];
+                    pmy[q] = from_lane_below(pb[q] + 0.25 * gyb[q]);
+                    ppy[q] = pb[q] - 0.25 * gyb[q];
                 }
-                double c2l = from_lane_below(c2b);
-                gam_hlle2<1>(pmy, ppy, c2l, c2b, gamma, GR, GL);
+                double csl = from_lane_below(csb);
+                gam_hlle2_fast<1>(pmy, ppy, csl, csb, P.inv_gm1, GR, GL);
                 if (visc) {
-                    double rhol = from_lane_below(pb[0]);
-                    double vxl = from_lane_below(pb[1]);
-                    double vyl = from_lane_below(pb[2]);
-                    double syxl = from_lane_below(sxy);
-                    double syyl = from_lane_below(syy);
+                    double txb = pb[0] * sxy, tyb = pb[0] * syy;          // rho tau^y_x, rho tau^y_y of this zone
+                    double exb = txb * pb[1] + tyb * pb[2];
+                    double txl = from_lane_below(txb), tyl = from_lane_below(tyb), exl = from_lane_below(exb);
                     double qhl = from_lane_below(qhb);
                     double nul = from_lane_below(nub);
-                    double om2f = gam_omega2(P.m, xcb, yf);
-                    double nufL = P.alpha * gam_height(qhl, om2f) * sqrt(c2l); // cbdgam_2d.c:641,647
-                    double nufR = P.alpha * gam_height(qhb, om2f) * sqrt(c2b); // cbdgam_2d.c:642,648
-                    GR[1] -= 0.5 * (nufL * rhol * syxl + nub * pb[0] * sxy);
-                    GR[2] -= 0.5 * (nufL * rhol * syyl + nub * pb[0] * syy);
-                    GR[3] -= 0.5 * (nufL * rhol * syxl * vxl + nub * pb[0] * sxy * pb[1]);
-                    GR[3] -= 0.5 * (nufL * rhol * syyl * vyl + nub * pb[0] * syy * pb[2]);
-                    GL[1] -= 0.5 * (nul * rhol * syxl + nufR * pb[0] * sxy);
-                    GL[2] -= 0.5 * (nul * rhol * syyl + nufR * pb[0] * syy);
-                    GL[3] -= 0.5 * (nul * rhol * syxl * vxl + nufR * pb[0] * sxy * pb[1]);
-                    GL[3] -= 0.5 * (nul * rhol * syyl * vyl + nufR * pb[0] * syy * pb[2]);
+                    double iof = hvar ? gam_inv_omega_fast(P.m, xcb, oyf0, oyf1) : 1.0;
+                    double nufL = P.alpha * (hvar ? qhl * iof : 1.0) * csl; // cbdgam_2d.c:641,647
+                    double nufR = P.alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:642,648
+                    GR[1] -= 0.5 * (nufL * txl + nub * txb);
+                    GR[2] -= 0.5 * (nufL * tyl + nub * tyb);
+                    GR[3] -= 0.5 * (nufL * exl + nub * exb);
+                    GL[1] -= 0.5 * (nul * txl + nufR * txb);
+                    GL[2] -= 0.5 * (nul * tyl + nufR * tyb);
+                    GL[3] -= 0.5 * (nul * exl + nufR * exb);
                 }
                 // upper face of this zone is the lower face of lane j+1, seen from below
 #pragma unroll
@@ -314,47 +428,66 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
             if (r - 2 >= I0) {
                 // update row r-2 (cbdgam_2d.c:669-681)
                 const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
+                const double rinva = fast_rcp(pa[0]);
+                const double eps = pa[3] * rinva * P.inv_gm1;
                 double u[4];
-                gam_p2c(pa, u, gamma);
+                u[0] = pa[0]; u[1] = pa[1] * pa[0]; u[2] = pa[2] * pa[0];
+                u[3] = pa[3] * P.inv_gm1 + 0.5 * pa[0] * (pa[1] * pa[1] + pa[2] * pa[2]);
                 // disk_height at the zone centre is only consumed by non-constant softening
                 double hcc = 1.0;
-                if (!P.constant_softening) hcc = gam_height(sqrt(pa[3] / pa[0]), gam_omega2(P.m, xc, yc));
-                gam_buffer(P, xc, yc, u);
-                gam_mass_source(P.m[0], xc, yc, P.dt, pa, hcc, u, P.constant_softening, gamma);
-                gam_mass_source(P.m[1], xc, yc, P.dt, pa, hcc, u, P.constant_softening, gamma);
-                gam_cooling(P, pa, u);
+                if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast(P.m, xc, oyc0, oyc1);
+                gam_buffer_fast(P, xc, yc, yc2, u);
+                gam_mass_source_fast(P.m[0], xc, dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_mass_source_fast(P.m[1], xc, dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_cooling_fast(P, pa, eps, rinva, u);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) u[q] -= ((FL[q] - Fp[q]) / P.dx + dGp[q] / P.dy) * P.dt;
+                for (int q = 0; q < 4; ++q) u[q] -= ((FL[q] - Fp[q]) * P.inv_dx + dGp[q] * P.inv_dy) * P.dt;
                 const long c = (long)(r - 2) * si + (long)J * sj;
-                if (P.un_mode && store_lane) {
-                    double un[4] = {unsrc[c], unsrc[c + 1], unsrc[c + 2], unsrc[c + 3]};
-                    if (P.un_mode == 2) { double t[4]; gam_p2c(un, t, gamma); un[0] = t[0]; un[1] = t[1]; un[2] = t[2]; un[3] = t[3]; }
+                if (UN) {
+                    double w[4] = {un[0], un[1], un[2], un[3]};
+                    if (P.un_mode == 2) { // u^n = p2c(p^n), cbdgam_2d.c:347-362
+                        w[3] = un[3] * P.inv_gm1 + 0.5 * un[0] * (un[1] * un[1] + un[2] * un[2]);
+                        w[1] = un[1] * un[0];
+                        w[2] = un[2] * un[0];
+                    }
+                    const double b = 1.0 - P.a;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) u[q] = (1.0 - P.a) * u[q] + P.a * un[q];
+                    for (int q = 0; q < 4; ++q) u[q] = b * u[q] + P.a * w[q];
                 }
                 // cbdgam_2d.c:319-345
-                double pres = max2(P.pfloor, (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) / u[0]) * (gamma - 1.0));
-                double vx = copysign(1.0, u[1]) * min2(fabs(u[1] / u[0]), P.vmax);
-                double vy = copysign(1.0, u[2]) * min2(fabs(u[2] / u[0]), P.vmax);
+                double rinv = fast_rcp(u[0]);
+                double pres = __builtin_fmax(P.pfloor, (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) * rinv) * P.gm1);
+                double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
+                double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
                 double rho = u[0];
                 if (u[0] < P.dfloor) { rho = P.dfloor; vx = 0.0; vy = 0.0; pres = P.pfloor; }
                 if (store_lane) {
                     pwr[c] = rho; pwr[c + 1] = vx; pwr[c + 2] = vy; pwr[c + 3] = pres;
-                    if (P.want_wavespeed) amax = max2(amax, max_speed(vx, vy, pres / rho * gamma));
+                    if (WS) {
+                        // same filter as the isothermal kernel: a ~1-ulp estimate decides which zones
+                        // get the IEEE evaluation, so the reduced maximum is bit-exact
+                        double pre = pres * fast_rcp(rho) * gamma;
+                        double cse = sqrt_from_rsqrt(pre, fast_rsqrt(pre));
+                        if ((__builtin_fmax(fabs(vx), fabs(vy)) + cse) * (1.0 + 1e-9) >= athr) {
+#pragma clang fp contract(off)
+                            amax = max2(amax, max_speed(vx, vy, pres / rho * gamma));
+                            athr = max2(athr, amax);
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                pmx[q] = pb[q] + 0.5 * gxb[q];
+                pmx[q] = pb[q] + 0.25 * gxb[q];
                 Fp[q] = FR[q];
                 dGp[q] = dG[q];
             }
-            sxxa = sxx; sxya = sxy; c2a = c2b; qha = qhb; nua = nub;
+            sxxa = sxx; sxya = sxy; csa = csb; qha = qhb; nua = nub;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { gyb[q] = gyc[q]; pa[q] = pb[q]; pb[q] = pc[q]; }
     }
-    if (P.want_wavespeed) {
+    if (WS) {
         amax = wave_max_nonneg(amax);
         if (lane == 0) atomic_max_nonneg(wmax, amax);
     }

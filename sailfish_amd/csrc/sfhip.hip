@@ -118,7 +118,9 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = 4;
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    hipLaunchKernelGGL(sf::gam_stage_kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
+    auto kernel = P.want_wavespeed ? (P.un_mode ? sf::gam_stage_kernel<true, true> : sf::gam_stage_kernel<true, false>)
+                                   : (P.un_mode ? sf::gam_stage_kernel<false, true> : sf::gam_stage_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
     return check_launch("cbdgam_2d stage launch");
 }
 
@@ -165,15 +167,25 @@ void fill_gam(sf::GamParams &P, int ni, int nj, double pxl, double pxr, double p
     P.xl = pxl; P.yl = pyl;
     P.dx = (pxr - pxl) / ni; // cbdgam_2d.c:498-499
     P.dy = (pyr - pyl) / nj;
+    P.inv_dx = 1.0 / P.dx;
+    P.inv_dy = 1.0 / P.dy;
     P.m[0] = m1; P.m[1] = m2;
+    P.any_mass = !(m1.mass == 0.0 && m2.mass == 0.0); // cbdgam_2d.c:81
     P.gamma = gamma;
+    P.gm1 = gamma - 1.0;
+    P.inv_gm1 = 1.0 / (gamma - 1.0);
+    P.sqrt_gamma = sqrt(gamma);
     P.buf_sd = bsd; P.buf_sp = bsp; P.buf_mc = bmc; P.buf_rate = brate; P.buf_rout = brout;
     P.buf_ron = brout - bw;                               // cbdgam_2d.c:255
     P.buf_omega = sqrt(bmc * pow(P.buf_ron, -3.0));       // cbdgam_2d.c:266
+    P.buf_ron2 = P.buf_ron * P.buf_ron;
+    P.buf_rate_scale = brate * P.buf_omega / (brout - P.buf_ron); // cbdgam_2d.c:268
+    P.buf_e0 = bsp / (gamma - 1.0);                       // cbdgam_2d.c:263
     P.buf_on = bon;
     P.constant_softening = constant_softening;
     P.alpha = alpha; P.a = a; P.dt = dt; P.vmax = vmax; P.cooling = cooling;
     P.mach_ceiling_m2 = pow(mach_ceiling, -2.0);          // cbdgam_2d.c:314
+    P.mach_floor_scale = 2.0 / gamma / (gamma - 1.0) * P.mach_ceiling_m2;
     P.dfloor = dfloor; P.pfloor = pfloor;
     P.un_mode = a != 0.0 ? 1 : 0;
     P.i_begin = 0; P.i_end = ni;
