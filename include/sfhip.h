@@ -53,6 +53,16 @@ SFHIP_API int sfhip_selftest_fastmath(
     double *out3n) // :: $.numel() >= 3 * n
 ;
 
+/* The driver's `dt = dx / amax * cfl` (driver.py:509-510) evaluated on the device
+ * with the same IEEE operations, from the reduced wavespeed; n must be 1. */
+SFHIP_API int sfhip_timestep(
+    int n,
+    double dx,
+    double cfl,
+    double *wavespeed_max, // :: $.numel() >= 1
+    double *dt_out) // :: $.numel() >= 1
+;
+
 /* Replaces `self.wavespeeds.max()` (cbdiso_2d.py:174, cbdgam_2d.py:152): max of
  * n non-negative doubles into *out (device scalar). */
 SFHIP_API int sfhip_max_nonneg(
@@ -185,7 +195,9 @@ SFHIP_API int cbdiso_2d_wavespeed(
  * speed is below it are not folded in, so the reduced value is the exact global
  * maximum whenever it comes out >= wavespeed_floor (after the cross-rank MAX); a
  * caller that sees a smaller value recomputes with *_max_wavespeed.  Pass 0 to
- * fold every zone. */
+ * fold every zone.  dt_device, when not NULL, overrides `dt` with a timestep that
+ * sfhip_timestep left in device memory, so the first stage of a step can be
+ * launched before the host has read the wavespeed back. */
 SFHIP_API int sfhip_cbdiso_2d_stage(
     int ni,
     int nj,
@@ -243,7 +255,8 @@ SFHIP_API int sfhip_cbdiso_2d_stage(
     double wy2,
     double wmass2,
     double wsoftening_length2,
-    double *wavespeed_max) // :: $.numel() >= 1
+    double *wavespeed_max, // :: $.numel() >= 1
+    double *dt_device) // :: $.numel() >= 1
 ;
 
 /* Wavespeed kernel + max in one pass (no per-zone array): replaces the pair
@@ -426,7 +439,8 @@ SFHIP_API int sfhip_cbdgam_2d_stage(
     int i_end, // :: i_begin <= $ <= ni
     int want_wavespeed, // :: $ in [0, 1, 2]
     double wavespeed_floor, // :: $ >= 0.0
-    double *wavespeed_max) // :: $.numel() >= 1
+    double *wavespeed_max, // :: $.numel() >= 1
+    double *dt_device) // :: $.numel() >= 1
 ;
 
 SFHIP_API int sfhip_cbdgam_2d_max_wavespeed(

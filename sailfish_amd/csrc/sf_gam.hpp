@@ -35,6 +35,7 @@ struct GamParams {
     int clamp_ilo, clamp_ihi, clamp_j, un_mode;
     int rows_per_chunk, i_begin, i_end, want_wavespeed;
     double ws_floor; // zones slower than this are not folded in (see include/sfhip.h)
+    const double *dt_ptr;       // when set, the timestep is read from device memory instead of `dt`
 };
 
 // ---- exact pieces (reference-named small kernels, wavespeed/dt path) -------
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
     const int strip = gw % nstrips;
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return;
+    if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
 
     const int ni = P.ni, nj = P.nj;
     const long sj = 4, si = 4L * (nj + 2 * NG);

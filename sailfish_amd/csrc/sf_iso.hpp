@@ -43,6 +43,7 @@ struct IsoParams {
     int i_begin, i_end;         // zone-row range [i_begin, i_end) to update (interior/boundary split for halo overlap)
     int want_wavespeed;         // fold max wavespeed of the OUTPUT state into *wmax
     double ws_floor;            // zones slower than this are not folded in (see include/sfhip.h)
+    const double *dt_ptr;       // when set, the timestep is read from device memory instead of `dt`
     Mass mw[2];                 // masses at the time the output state belongs to (for want_wavespeed)
 };
 
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
     const int strip = gw % nstrips;
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return; // whole wave leaves together
+    if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
 
     const int ni = P.ni, nj = P.nj;
     const long sj = 3, si = 3L * (nj + 2 * NG);

@@ -211,6 +211,13 @@ __global__ void lane_shift_kernel(const double *in, double *out_below, double *o
     out_above[t] = sf::from_lane_above(x);
 }
 
+// dt = dx / amax * cfl in exactly the reference driver's operation order (driver.py:509-510), IEEE ops
+__global__ void timestep_kernel(double dx, double cfl, const double *amax, double *dt)
+{
+#pragma clang fp contract(off)
+    if (threadIdx.x == 0 && blockIdx.x == 0) dt[0] = dx / amax[0] * cfl;
+}
+
 // fast-math self test: out[0..n) = fast_rcp(x), out[n..2n) = fast_rsqrt(x), out[2n..3n) = sqrt via rsqrt
 __global__ void fastmath_kernel(const double *x, double *out, int n)
 {
@@ -257,6 +264,13 @@ int sfhip_selftest_lane_shift(const double *in64, double *out_below64, double *o
 {
     hipLaunchKernelGGL(lane_shift_kernel, dim3(1), dim3(64), 0, t_stream, in64, out_below64, out_above64);
     return check_launch("lane_shift_kernel");
+}
+
+int sfhip_timestep(int n, double dx, double cfl, double *wavespeed_max, double *dt_out)
+{
+    if (n != 1 || !wavespeed_max || !dt_out) return fail(-1, "sfhip_timestep: bad arguments");
+    hipLaunchKernelGGL(timestep_kernel, dim3(1), dim3(64), 0, t_stream, dx, cfl, wavespeed_max, dt_out);
+    return check_launch("timestep_kernel");
 }
 
 int sfhip_selftest_fastmath(int n, double *x, double *out3n)
@@ -320,7 +334,7 @@ int sfhip_cbdiso_2d_stage(
     double wavespeed_floor,
     double wx1, double wy1, double wmass1, double wsoftening_length1,
     double wx2, double wy2, double wmass2, double wsoftening_length2,
-    double *wavespeed_max)
+    double *wavespeed_max, double *dt_device)
 {
     sf::IsoParams P;
     fill_iso(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
@@ -336,6 +350,7 @@ int sfhip_cbdiso_2d_stage(
     P.ws_floor = wavespeed_floor;
     P.mw[0] = make_mass(wx1, wy1, 0, 0, wmass1, wsoftening_length1, 0, 0, 0);
     P.mw[1] = make_mass(wx2, wy2, 0, 0, wmass2, wsoftening_length2, 0, 0, 0);
+    P.dt_ptr = dt_device;
     return launch_iso_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
 }
 
@@ -452,7 +467,7 @@ int sfhip_cbdgam_2d_stage(
     double alpha, double a, double dt, double velocity_ceiling, double cooling_coefficient,
     double mach_ceiling, double density_floor, double pressure_floor, int constant_softening,
     int un_mode, int clamp_ilo, int clamp_ihi, int i_begin, int i_end, int want_wavespeed,
-    double wavespeed_floor, double *wavespeed_max)
+    double wavespeed_floor, double *wavespeed_max, double *dt_device)
 {
     sf::GamParams P;
     fill_gam(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, gamma_law_index,
@@ -467,6 +482,7 @@ int sfhip_cbdgam_2d_stage(
     P.i_begin = i_begin; P.i_end = i_end;
     P.want_wavespeed = want_wavespeed;
     P.ws_floor = wavespeed_floor;
+    P.dt_ptr = dt_device;
     return launch_gam_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
 }
 

@@ -46,6 +46,13 @@ class KernelInvocation:
         self.shape = tuple(int(n) for n in shape)
 
     def __call__(self, *args):
+        self.bind(*args)()
+
+    def bind(self, *args):
+        """
+        Validate and marshal now, launch later: returns a zero-argument callable that performs
+        only the C call.  (Lets a caller put its timing events right around the launch.)
+        """
         lib = self.kernel.lib
         sym = self.kernel.symbol
         args = list(self.shape) + list(args)
@@ -54,10 +61,16 @@ class KernelInvocation:
             validate_constraints(args, sym.args, sym.name)
         elif len(args) != len(sym.args):
             raise arglen_error(sym.name, args, sym.args)
-        lib.bind_stream(args)
-        status = self.kernel.cfunc(*to_ctypes(args, sym.args))
-        if status != 0:
-            raise KernelError(f"{sym.name} failed ({status}): {lib.last_error()}")
+        cargs = to_ctypes(args, sym.args)
+        cfunc = self.kernel.cfunc
+
+        def fire():
+            lib.bind_stream(args)
+            status = cfunc(*cargs)
+            if status != 0:
+                raise KernelError(f"{sym.name} failed ({status}): {lib.last_error()}")
+
+        return fire
 
 
 class Kernel:

@@ -266,6 +266,7 @@ class SolverBase:
         self._comm_stream = None
         self._mass_cache = (None, None)
         self._wavespeed_floor = 0.0
+        self._dt_dev = None
         self.event_log = None  # bench.py sets this to a list to time every stage launch with HIP events
 
     def _patch_kwargs(self):
@@ -325,20 +326,18 @@ class SolverBase:
         return value
 
     def _reduce_wavespeed(self, recompute):
+        same_device = len({str(p.wavespeed_max.device) for p in self.patches}) == 1
+        if same_device:
+            return float(self._reduce_wavespeed_device(recompute).item())
+        # patches spread over several devices of one process: reduce on the host, as the reference does
         if recompute:
             for p in self.patches:
                 with p.execution_context:
                     p.launch_maximum_wavespeed(self.point_masses(p.time))
                 p.wavespeed_valid = True
-        if len(self.patches) == 1:
-            local = self.patches[0].wavespeed_max
-        else:
-            dev = self.patches[0].wavespeed_max.device
-            local = self.patches[0].wavespeed_max.clone()
-            for p in self.patches[1:]:
-                local = self._torch().maximum(local, p.wavespeed_max.to(dev))
+        local = self._torch().tensor([max(float(p.wavespeed_max.item()) for p in self.patches)],
+                                     dtype=self._torch().float64, device=self.patches[0].wavespeed_max.device)
         if self.comm.enabled:
-            local = local.clone()
             self.comm.max_scalar(local)
         return float(local.item())
 
@@ -364,7 +363,7 @@ class SolverBase:
             with p.execution_context:
                 p.new_iteration()
 
-    def advance_rk(self, rk_param, dt, stage=0, nstages=1):
+    def advance_rk(self, rk_param, dt, stage=0, nstages=1, dt_device=None):
         if not self.fused:
             self.set_bc("primitive1")
             for p in self.patches:
@@ -384,29 +383,96 @@ class SolverBase:
             next_masses = self.point_masses(p.stage_time(rk_param, dt)) if last_stage else masses
             plans.append((p, lo, hi, rd, un, wr, masses, next_masses))
             with p.execution_context:
-                self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, lo, hi, 2 if last_stage else 0)
+                self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, lo, hi, 2 if last_stage else 0,
+                             dt_device)
         self.finish_halo_exchange(pending)
         for p, lo, hi, rd, un, wr, masses, next_masses in plans:
             ni = p.shape[0]
             with p.execution_context:
                 if lo > 0:
-                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, 0, lo, 1 if last_stage else 0)
+                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, 0, lo, 1 if last_stage else 0,
+                                 dt_device)
                 if hi < ni:
-                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, hi, ni, 1 if last_stage else 0)
-            p.finish_stage(rk_param, dt, wr)
+                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, hi, ni, 1 if last_stage else 0,
+                                 dt_device)
+            if dt_device is None:
+                p.finish_stage(rk_param, dt, wr)
             p.wavespeed_valid = last_stage
+        return [plan[5] for plan in plans]
 
-    def _launch(self, p, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed):
+    def step(self, cfl_number, dx=None):
+        """
+        One driver iteration -- ``dt = dx / maximum_wavespeed() * cfl; advance(dt)`` (driver.py:508-511)
+        -- with the wavespeed read-back taken off the critical path: dt is also evaluated on the device
+        (same IEEE operations, sfhip_timestep), the first RK stage is launched against that device value,
+        and only then does the host read the wavespeed back to form the identical dt for its own
+        bookkeeping (time, point-mass positions of the later stages).  Returns dt.
+        """
+        dx = self.mesh.min_spacing() if dx is None else dx
+        params = self.rk_parameters()
+        same_device = len({str(p.wavespeed_max.device) for p in self.patches}) == 1
+        if not (self.fused and len(params) > 1 and same_device and hasattr(self.patches[0].lib, "sfhip_timestep")):
+            dt = dx / self.maximum_wavespeed() * cfl_number
+            self.advance(dt)
+            return dt
+
+        floor = self._wavespeed_floor
+        have_fused = all(p.wavespeed_valid for p in self.patches)
+        while True:
+            amax_dev = self._reduce_wavespeed_device(recompute=not have_fused)
+            p0 = self.patches[0]
+            if self._dt_dev is None:
+                with p0.execution_context:
+                    self._dt_dev = p0.xp.zeros(1)
+            with p0.execution_context:
+                p0.lib.sfhip_timestep[1](float(dx), float(cfl_number), amax_dev, self._dt_dev)
+            self.new_iteration()
+            # dt is not known on the host yet: nothing below may depend on it (stage 0 never does)
+            wrote = self.advance_rk(params[0], float("nan"), 0, len(params), dt_device=self._dt_dev)
+            amax = float(amax_dev.item())  # the one device->host sync of the step, overlapped with stage 0
+            if have_fused and amax < floor:
+                have_fused = False  # the filtered maximum is only a lower bound: recompute exactly and redo stage 0
+                continue
+            break
+        self._wavespeed_floor = 0.5 * amax
+        dt = dx / amax * cfl_number
+        for p, wr in zip(self.patches, wrote):
+            p.finish_stage(params[0], dt, wr)
+        for stage in range(1, len(params)):
+            self.advance_rk(params[stage], dt, stage, len(params))
+        return dt
+
+    def _reduce_wavespeed_device(self, recompute):
+        """Max wavespeed over local patches and ranks as a device scalar; nothing here blocks the host."""
+        if recompute:
+            for p in self.patches:
+                with p.execution_context:
+                    p.launch_maximum_wavespeed(self.point_masses(p.time))
+                p.wavespeed_valid = True
+        local = self.patches[0].wavespeed_max
+        if len(self.patches) > 1 or self.comm.enabled:
+            local = local.clone()
+            for p in self.patches[1:]:
+                local = self._torch().maximum(local, p.wavespeed_max)
+        if self.comm.enabled:
+            self.comm.max_scalar(local)
+        return local
+
+    def _launch(self, p, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed,
+                dt_device=None):
         """One stage-kernel launch on patch `p`, optionally bracketed by HIP events on its stream."""
         floor = self._wavespeed_floor
         if self.event_log is None:
-            p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor)
+            p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor,
+                           dt_device=dt_device)
             return
         torch = self._torch()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
+        fire = p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor,
+                              defer=True, dt_device=dt_device)
         e0.record()
-        p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor)
+        fire()
         e1.record()
         self.event_log.append(dict(zones=(i_end - i_begin) * p.shape[1], reads_un=un is not None, start=e0, stop=e1))
 

@@ -108,15 +108,18 @@ class Patch(PatchBase):
             self.lib.sfhip_max_nonneg[self.wavespeeds.numel()](self.wavespeeds, self.wavespeed_max)
 
     def launch_stage(self, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed,
-                     wavespeed_floor=0.0):
+                     wavespeed_floor=0.0, defer=False, dt_device=None):
         m1, m2 = masses
-        self.lib.sfhip_cbdgam_2d_stage[self.shape](
+        fire = self.lib.sfhip_cbdgam_2d_stage[self.shape].bind(
             *self._extent(), un, rd, wr,
             *self._head_args(m1, m2), *m1.kernel_args(), *m2.kernel_args(),
             *self._tail_args(rk_param, dt),
             2 if un is not None else 0, int(self.first), int(self.last), i_begin, i_end, want_wavespeed,
-            wavespeed_floor, self.wavespeed_max,
+            wavespeed_floor, self.wavespeed_max, dt_device,
         )
+        if defer:
+            return fire
+        fire()
 
 
 class Solver(SolverBase):

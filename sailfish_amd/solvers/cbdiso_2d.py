@@ -115,10 +115,10 @@ class Patch(PatchBase):
             self.lib.sfhip_max_nonneg[self.wavespeeds.numel()](self.wavespeeds, self.wavespeed_max)
 
     def launch_stage(self, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed,
-                     wavespeed_floor=0.0):
+                     wavespeed_floor=0.0, defer=False, dt_device=None):
         m1, m2 = masses
         w1, w2 = next_masses
-        self.lib.sfhip_cbdiso_2d_stage[self.shape](
+        fire = self.lib.sfhip_cbdiso_2d_stage[self.shape].bind(
             *self._extent(), un, rd, wr,
             *self._buffer_args(m1, m2), *m1.kernel_args(), *m2.kernel_args(),
             *self._tail_args(rk_param, dt),
@@ -126,8 +126,11 @@ class Patch(PatchBase):
             wavespeed_floor,
             w1.position_x, w1.position_y, w1.mass, w1.softening_length,
             w2.position_x, w2.position_y, w2.mass, w2.softening_length,
-            self.wavespeed_max,
+            self.wavespeed_max, dt_device,
         )
+        if defer:
+            return fire
+        fire()
 
 
 class Solver(SolverBase):

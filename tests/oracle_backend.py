@@ -24,6 +24,9 @@ class _Invocation:
     def __init__(self, lib, name, shape):
         self.lib, self.name, self.shape = lib, name, tuple(shape)
 
+    def bind(self, *args):
+        return lambda: self(*args)
+
     def __call__(self, *args):
         sym = _oracle.API[self.name]
         names = [a.name for a in sym.args][len(self.shape):]
@@ -72,6 +75,10 @@ class OracleLibrary:
             out_t.zero_()
         out_t[0] = max(float(out_t[0]), value)
 
+    def _sfhip_timestep(self, shape, kw, args):
+        with np.errstate(divide="ignore"):  # amax == 0 gives inf on the device too
+            kw["dt_out"][0] = float(np.float64(kw["dx"]) / np.float64(kw["wavespeed_max"][0]) * np.float64(kw["cfl"]))
+
     # -- cbdiso -------------------------------------------------------------
     def _sfhip_cbdiso_2d_stage(self, shape, kw, args):
         ni, nj = shape
@@ -84,6 +91,8 @@ class OracleLibrary:
         out = np.zeros_like(rd)
         ref_args = list(args[:41 - 2])  # the 39 arguments after (ni, nj) shared with cbdiso_2d_advance_rk
         ref_args[4], ref_args[5], ref_args[6] = cons, rd, out
+        if kw["dt_device"] is not None:
+            ref_args[36] = float(kw["dt_device"][0])
         self.orc.call("cbdiso_2d_advance_rk", shape, *ref_args)
         i0, i1 = kw["i_begin"] + NG, kw["i_end"] + NG
         _np(kw["primitive_wr"])[i0:i1, NG:-NG] = out[i0:i1, NG:-NG]
@@ -118,6 +127,8 @@ class OracleLibrary:
         out = np.zeros_like(rd)
         ref_args = list(args[:44 - 2])
         ref_args[4], ref_args[5], ref_args[6] = cons, rd, out
+        if kw["dt_device"] is not None:
+            ref_args[35] = float(kw["dt_device"][0])
         self.orc.call("cbdgam_2d_advance_rk", shape, *ref_args)
         i0, i1 = kw["i_begin"] + NG, kw["i_end"] + NG
         _np(kw["primitive_wr"])[i0:i1, NG:-NG] = out[i0:i1, NG:-NG]

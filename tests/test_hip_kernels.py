@@ -162,12 +162,15 @@ def test_iso_fused_stage_equals_reference_sequence(hip_lib, orc, a, shape, floor
     d_pn = dev(pn)
     wmax = torch.full((1,), 55.0, dtype=torch.float64, device="cuda")
     cut1, cut2 = 2, ni - 2
+    d_dt = torch.full((1,), c["dt"], dtype=torch.float64, device="cuda")
     for k, (i0, i1) in enumerate([(cut1, cut2), (0, cut1), (cut2, ni)]):
+        # the boundary-row launches take dt from device memory (dt_device overrides the scalar)
         hip_lib.sfhip_cbdiso_2d_stage[c["shape"]](
             *c["extent"], d_pn if a != 0.0 else None, d_rd, d_pn,
-            *c["buffer"], *c["m1"], *c["m2"], *c["eos"], c["nu"], c["a"], c["dt"], c["vmax"], c["dfloor"],
+            *c["buffer"], *c["m1"], *c["m2"], *c["eos"], c["nu"], c["a"],
+            c["dt"] if k == 0 else float("nan"), c["vmax"], c["dfloor"],
             2, 1, 1, i0, i1, 2 if k == 0 else 1, floor,
-            w1[0], w1[1], w1[4], w1[5], w2[0], w2[1], w2[4], w2[5], wmax)
+            w1[0], w1[1], w1[4], w1[5], w2[0], w2[1], w2[4], w2[5], wmax, None if k == 0 else d_dt)
     got = host(d_pn)
     err = cases.zone_relative_error(got, expect)
     assert err <= ADVANCE_TOL, err

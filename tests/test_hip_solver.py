@@ -115,3 +115,40 @@ def test_restart_from_solution_is_bitwise():
         dt = timestep(mesh, s, 0.3)
         s.advance(dt)
     assert np.array_equal(a.solution, b.solution)
+
+
+@pytest.mark.parametrize("name,model,num_patches", [
+    ("circumbinary-disk", {}, 1), ("circumbinary-disk", {}, 4), ("circumbinary-disk", dict(eos="gamma-law"), 2),
+])
+def test_step_equals_timestep_then_advance_bitwise(name, model, num_patches):
+    """Solver.step(cfl) (dt formed on the device, read-back overlapped with stage 0) == the reference
+    driver's two blocking calls (driver.py:508-511), bit for bit, dt sequence included."""
+    setup = make_setup(name, **model)
+    mesh = setup.mesh(96)
+    kw = dict(setup=setup, mesh=mesh, time=0.0, num_patches=num_patches, mode="hip")
+    a = make_solver(setup.solver, setup.physics, {}, **kw)
+    b = make_solver(setup.solver, setup.physics, {}, **kw)
+    cfl = a.recommended_cfl
+    for _ in range(8):
+        dt_a = a.step(cfl)
+        dt_b = timestep(mesh, b, cfl)
+        b.advance(dt_b)
+        assert dt_a == dt_b and a.time == b.time
+    assert np.array_equal(a.solution, b.solution)
+
+
+def test_step_redoes_stage_when_filtered_wavespeed_is_below_floor():
+    setup = make_setup("circumbinary-disk")
+    mesh = setup.mesh(64)
+    kw = dict(setup=setup, mesh=mesh, time=0.0, mode="hip")
+    a = make_solver(setup.solver, setup.physics, {}, **kw)
+    b = make_solver(setup.solver, setup.physics, {}, **kw)
+    for s in (a, b):
+        s.maximum_wavespeed()
+        s._wavespeed_floor = 1e6  # the fused epilogue of the next advance folds nothing
+        s.advance(1e-3)
+    dt_a = a.step(0.3)
+    dt_b = timestep(mesh, b, 0.3)
+    b.advance(dt_b)
+    assert dt_a == dt_b and a.time == b.time
+    assert np.array_equal(a.solution, b.solution)

@@ -164,3 +164,51 @@ def test_wavespeed_floor_fallback():
     fresh = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=s.time, solution=s.solution,
                         backend=OracleBackend(), distributed=False)
     assert a1 == fresh.maximum_wavespeed() and a1 > 0.0
+
+
+@pytest.mark.parametrize("name,num_patches", [
+    ("iso_disk_64", 1), ("iso_disk_128_p4", 4), ("iso_disk_rk3_48", 3), ("gam_disk_64", 1), ("gam_explosion_64", 4),
+])
+def test_step_with_device_side_dt_reproduces_reference_bitwise(name, num_patches):
+    """Solver.step(cfl) -- dt formed on the device, read-back overlapped with stage 0 -- gives the same
+    dt sequence, times and final state as the reference's `dt = dx / amax * cfl; advance(dt)`."""
+    from oracle_backend import OracleBackend
+    from sailfish_amd.setups import make_setup
+    from sailfish_amd.solvers import make_solver
+    from test_golden_cpu import CASES, load
+
+    setup_name, model, options = CASES[name]
+    g = load(name)
+    setup = make_setup(setup_name, **model)
+    mesh = setup.mesh(int(g["resolution"]))
+    s = make_solver(setup.solver, setup.physics, options, setup=setup, mesh=mesh, time=0.0,
+                    num_patches=num_patches, backend=OracleBackend(), distributed=False)
+    for dt_ref, t_ref in zip(g["dt"], g["time"]):
+        assert s.step(float(g["cfl"])) == dt_ref
+        assert s.time == t_ref
+    assert np.array_equal(s.solution, g["final"])
+
+
+def test_step_redoes_stage_when_filtered_wavespeed_is_below_floor():
+    """step() launches stage 0 before it knows the wavespeed; a filtered (too small) value must be
+    recomputed exactly and the stage redone, leaving the same state as the blocking path."""
+    from oracle_backend import OracleBackend
+    from sailfish_amd.driver import timestep
+    from sailfish_amd.setups import make_setup
+    from sailfish_amd.solvers import make_solver
+
+    setup = make_setup("circumbinary-disk")
+    mesh = setup.mesh(32)
+    kw = dict(setup=setup, mesh=mesh, time=0.0, backend=OracleBackend(), distributed=False)
+    a = make_solver(setup.solver, setup.physics, {}, **kw)
+    b = make_solver(setup.solver, setup.physics, {}, **kw)
+    for s in (a, b):
+        s.maximum_wavespeed()
+        s._wavespeed_floor = 1e6  # the fused epilogue of the next advance folds nothing
+        s.advance(1e-3)
+        assert float(s.patches[0].wavespeed_max[0]) == 0.0
+    dt_a = a.step(0.3)
+    dt_b = timestep(mesh, b, 0.3)
+    b.advance(dt_b)
+    assert dt_a == dt_b and a.time == b.time
+    assert np.array_equal(a.solution, b.solution)
