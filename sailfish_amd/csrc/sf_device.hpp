@@ -25,21 +25,22 @@ struct Mass {
 // Cross-lane moves.  A wave marches down the rows of a 64-column strip with one
 // column per lane, so "the zone at j-1 / j+1" is the neighbouring lane.  gfx9
 // DPP wave shifts move a dword one lane up or down the whole wave in a single
-// VALU op (no LDS traffic); lanes shifted in at the wave ends keep their own
-// value and are never used (HALO lanes).
+// VALU op (no LDS traffic); the lane at the wave end that has no source lane reads
+// zero (bound_ctrl, so the move needs no prior copy of the destination) and its
+// value is never used (HALO lanes).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double from_lane_below(double x) // value held by lane-1
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double from_lane_above(double x) // value held by lane+1
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

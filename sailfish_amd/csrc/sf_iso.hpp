@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
 {
 #pragma clang fp contract(fast)
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // wave-uniform by construction: tell the compiler, so rows, branches and addresses stay scalar
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int strip = gw % nstrips;
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return; // whole wave leaves together

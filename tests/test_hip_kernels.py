@@ -50,8 +50,8 @@ def test_lane_shift_selftest(hip_lib):
     assert hip_lib.module.sfhip_selftest_lane_shift(
         ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(below.data_ptr()), ctypes.c_void_p(above.data_ptr())) == 0
     xh, b, a = host(x), host(below), host(above)
-    assert np.array_equal(b[1:], xh[:-1]) and b[0] == xh[0]
-    assert np.array_equal(a[:-1], xh[1:]) and a[-1] == xh[-1]
+    assert np.array_equal(b[1:], xh[:-1]) and b[0] == 0.0  # no source lane: bound_ctrl zero
+    assert np.array_equal(a[:-1], xh[1:]) and a[-1] == 0.0
 
 
 def test_fast_math_accuracy(hip_lib):
