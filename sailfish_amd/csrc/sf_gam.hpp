@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
     const double yc2 = yc * yc;
     const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
     const double hidx = 0.5 * P.inv_dx, hidy = 0.5 * P.inv_dy; // slopes are carried doubled
+    // 0.25 is not an inline constant on gfx9 (see sf_iso.hpp): keep it as an opaque SGPR operand
+    double quarter = 0.25;
+    asm volatile("" : "+s"(quarter));
 
     double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4], pn[4], un[4] = {0, 0, 0, 0}, unn[4] = {0, 0, 0, 0};
     double gyb[4] = {0, 0, 0, 0};
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                 // x-face between rows r-2 (L) and r-1 (R)
                 double ppx[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ppx[q] = pb[q] - 0.25 * gxb[q];
+                for (int q = 0; q < 4; ++q) ppx[q] = pb[q] - quarter * gxb[q];
                 gam_hlle2_fast<0>(pmx, ppx, csa, csb, P.inv_gm1, FR, FL);
                 if (visc) {
                     double iof = hvar ? gam_inv_omega_fast(P.m, xf, oyc0, oyc1) : 1.0;
@@ -403,8 +406,8 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                 double pmy[4], ppy[4], GR[4], GL[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pmy[q] = from_lane_below(pb[q] + 0.25 * gyb[q]);
-                    ppy[q] = pb[q] - 0.25 * gyb[q];
+                    pmy[q] = from_lane_below(pb[q] + quarter * gyb[q]);
+                    ppy[q] = pb[q] - quarter * gyb[q];
                 }
                 double csl = from_lane_below(csb);
                 gam_hlle2_fast<1>(pmy, ppy, csl, csb, P.inv_gm1, GR, GL);
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                pmx[q] = pb[q] + 0.25 * gxb[q];
+                pmx[q] = pb[q] + quarter * gxb[q];
                 Fp[q] = FR[q];
                 dGp[q] = dG[q];
             }

@@ -231,6 +231,10 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
     }
     const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
     const double hidx = 0.5 * P.inv_dx, hidy = 0.5 * P.inv_dy; // slopes are carried doubled
+    // 0.25 is not an inline constant on gfx9: as a literal it forces v_mov + v_fmac (VOP2) for every
+    // p +- 0.25 g.  Held opaquely in an SGPR pair it is a plain operand of a 3-address v_fma_f64.
+    double quarter = 0.25;
+    asm volatile("" : "+s"(quarter));
 
     double pa[3] = {1, 0, 0}, pb[3] = {1, 0, 0}, pc[3];
     double gyb[3] = {0, 0, 0};
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
                 // x-face between rows r-2 and r-1 (cbdiso_2d.c:536-541, 560-561, 579-582)
                 double ppx[3], c2, cs;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - 0.25 * gxb[q];
+                for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - quarter * gxb[q];
                 iso_sound_fast(P, P.m, xf, cyc0, cyc1, c2, cs);
                 iso_hlle<0>(pmx, ppx, c2, cs, F);
                 if (visc) {
@@ -304,8 +308,8 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
                 double pmy[3], ppy[3], G[3], c2, cs;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    pmy[q] = from_lane_below(pb[q] + 0.25 * gyb[q]);
-                    ppy[q] = pb[q] - 0.25 * gyb[q];
+                    pmy[q] = from_lane_below(pb[q] + quarter * gyb[q]);
+                    ppy[q] = pb[q] - quarter * gyb[q];
                 }
                 iso_sound_fast(P, P.m, xcb, cyf0, cyf1, c2, cs);
                 iso_hlle<1>(pmy, ppy, c2, cs, G);
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
             // slide the window: row r-1 becomes the lower side of the next x-face
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                pmx[q] = pb[q] + 0.25 * gxb[q];
+                pmx[q] = pb[q] + quarter * gxb[q];
                 Fp[q] = F[q];
                 dGp[q] = dG[q];
             }
