@@ -451,6 +451,100 @@ SFHIP_API int sfhip_cbdgam_2d_max_wavespeed(
     double *wavespeed_max) // :: $.numel() >= 1
 ;
 
+/* Replaces the arithmetic of Solver.reductions() for one patch (cbdiso_2d.py:370-503):
+ * the four Patch.point_mass_source_term launches (mass 1 / 2 x gravity-only /
+ * accretion-only, cbdiso_2d.py:376-379), the per-diagnostic temporaries of get_field
+ * (:383-478) and `f.sum()` (:486), fused into one pass over the primitive array.
+ * Masses are passed unscaled; the kernel forms the gravity-only (sink_rate = 0) and
+ * accretion-only (mass = 0) variants as Patch.point_mass_source_term does (:129-131).
+ * xcoord / ycoord are Patch.cell_center_coordinate_arrays (cbdiso_2d.py:96-103), the
+ * moment arms of torque, sigma_m1, eccentricity_vector, angular_momentum.
+ * spec holds 8 doubles per diagnostic: quantity code (0..2 = rate of conserved field
+ * q: "mdot", "fx", "fy"; 10 torque, 11 power, 12 sigma_m1, 13 eccentricity_vector,
+ * 14 angular_momentum, 15 mass), which_mass (1, 2, 3 = "both"), gravity, accretion,
+ * has_radial_cut, r0, r1, unused.  sums receives (re, im) per diagnostic, NOT yet
+ * multiplied by dx*dy (the caller does, after adding the patches, :499).
+ * workspace_len must be >= sfhip_reductions_workspace_len(ni, nj). Deterministic. */
+SFHIP_API int sfhip_cbdiso_2d_reductions(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double x1,
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2,
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *xcoord, // :: $.numel() >= ni
+    double *ycoord, // :: $.numel() >= nj
+    int num_diagnostics, // :: 1 <= $ <= 8
+    double *spec, // :: $.numel() >= 8 * num_diagnostics
+    int workspace_len,
+    double *workspace, // :: $.numel() >= workspace_len
+    double *sums) // :: $.numel() >= 2 * num_diagnostics
+;
+
+/* As above for cbdgam_2d (cbdgam_2d.py:341-443); quantity codes 0..3 are the rates
+ * of the four conserved fields. */
+SFHIP_API int sfhip_cbdgam_2d_reductions(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double x1,
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2,
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    int constant_softening,
+    double gamma_law_index,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 4)
+    double *xcoord, // :: $.numel() >= ni
+    double *ycoord, // :: $.numel() >= nj
+    int num_diagnostics, // :: 1 <= $ <= 8
+    double *spec, // :: $.numel() >= 8 * num_diagnostics
+    int workspace_len,
+    double *workspace, // :: $.numel() >= workspace_len
+    double *sums) // :: $.numel() >= 2 * num_diagnostics
+;
+
+/* Number of doubles the reductions entry points need in `workspace` for an (ni, nj) patch. */
+SFHIP_API int sfhip_reductions_workspace_len(
+    int ni,
+    int nj)
+;
+
 #ifdef __cplusplus
 }
 #endif

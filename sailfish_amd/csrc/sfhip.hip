@@ -16,6 +16,7 @@
 
 #include "sf_gam.hpp"
 #include "sf_iso.hpp"
+#include "sf_reduce.hpp"
 #include "sfhip.h"
 
 namespace {
@@ -532,6 +533,99 @@ int cbdgam_2d_point_mass_source_term(
     dim3 block(256), grid((nj + 255) / 256, ni);
     hipLaunchKernelGGL(sf::gam_mass_rate_kernel, grid, block, 0, t_stream, P, which_mass - 1, primitive, cons_rate);
     return check_launch("cbdgam_2d_point_mass_source_term");
+}
+
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// time-series diagnostics (Solver.reductions)
+// ---------------------------------------------------------------------------
+static void reductions_grid(int ni, int nj, dim3 *grid)
+{
+    const int bx = (nj + 255) / 256;
+    int by = ni < 1024 / bx ? ni : 1024 / bx; // about 1024 blocks: 4 per CU
+    if (by < 1) by = 1;
+    *grid = dim3(bx, by);
+}
+
+static int reductions_workspace_len(int ni, int nj)
+{
+    if (ni < 1 || nj < 1) return 0;
+    dim3 grid;
+    reductions_grid(ni, nj, &grid);
+    return (int)(grid.x * grid.y) * sf::RED_SLOTS;
+}
+
+template <int NQ>
+static int reductions_impl(const char *name, int ni, int nj, double pxl, double pxr, double pyl, double pyr,
+                           const sf::Mass &m1, const sf::Mass &m2, int constant_softening, double gamma,
+                           const double *primitive, const double *xcoord, const double *ycoord,
+                           int nd, const double *spec, int workspace_len, double *workspace, double *sums)
+{
+    if (ni < 1 || nj < 1 || !primitive || !xcoord || !ycoord || !spec || !workspace || !sums) return fail(-1, name);
+    if (nd < 1 || nd > sf::RED_MAXD) return fail(-1, "reductions: num_diagnostics must be in 1..8 per call");
+    if (workspace_len < reductions_workspace_len(ni, nj)) return fail(-1, "reductions: workspace too small");
+    sf::ReduceParams P;
+    memset(&P, 0, sizeof(P));
+    P.ni = ni; P.nj = nj;
+    P.xl = pxl; P.yl = pyl;
+    P.dx = (pxr - pxl) / ni;
+    P.dy = (pyr - pyl) / nj;
+    P.mg[0] = m1; P.mg[1] = m2;
+    P.ma[0] = m1; P.ma[1] = m2;
+    for (int w = 0; w < 2; ++w) {
+        P.mg[w].sink_rate = P.mg[w].sink_rate * 0.0; // sink_rate * accretion with accretion = False
+        P.ma[w].mass = P.ma[w].mass * 0.0;           // mass * gravity with gravity = False
+    }
+    P.v[0][0] = m1.vx; P.v[0][1] = m1.vy;
+    P.v[1][0] = m2.vx; P.v[1][1] = m2.vy;
+    P.gamma = gamma;
+    P.constant_softening = constant_softening;
+    dim3 grid, block(256);
+    reductions_grid(ni, nj, &grid);
+    hipLaunchKernelGGL(sf::reduce_kernel<NQ>, grid, block, 0, t_stream, P, primitive, xcoord, ycoord, spec, nd, workspace);
+    int rc = check_launch(name);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sf::reduce_final_kernel, dim3(1), dim3(256), 0, t_stream,
+                       (const double *)workspace, (int)(grid.x * grid.y), 2 * nd, sums);
+    return check_launch(name);
+}
+
+extern "C" {
+
+int sfhip_reductions_workspace_len(int ni, int nj) { return reductions_workspace_len(ni, nj); }
+
+int sfhip_cbdiso_2d_reductions(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double *primitive, double *xcoord, double *ycoord, int num_diagnostics, double *spec,
+    int workspace_len, double *workspace, double *sums)
+{
+    return reductions_impl<3>("sfhip_cbdiso_2d_reductions: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+        make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+        make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+        1, 0.0, primitive, xcoord, ycoord, num_diagnostics, spec, workspace_len, workspace, sums);
+}
+
+int sfhip_cbdgam_2d_reductions(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    int constant_softening, double gamma_law_index,
+    double *primitive, double *xcoord, double *ycoord, int num_diagnostics, double *spec,
+    int workspace_len, double *workspace, double *sums)
+{
+    return reductions_impl<4>("sfhip_cbdgam_2d_reductions: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+        make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+        make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+        constant_softening, gamma_law_index, primitive, xcoord, ycoord, num_diagnostics, spec,
+        workspace_len, workspace, sums);
 }
 
 } // extern "C"

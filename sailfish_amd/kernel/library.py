@@ -151,6 +151,10 @@ class Library:
     def last_error(self):
         return (self.module.sfhip_last_error() or b"").decode()
 
+    def reductions_workspace_len(self, ni, nj):
+        """Doubles of scratch the sfhip_*_reductions entry points need (a size query: returns a value, not a status)."""
+        return int(self.module.sfhip_reductions_workspace_len(int(ni), int(nj)))
+
     def bind_stream(self, args):
         """
         Point the library at torch's current stream on the device that holds the

@@ -42,6 +42,15 @@ logger = getLogger(__name__)
 
 NG = 2  # guard zones per side
 
+# quantity codes of the reductions kernels' spec array (csrc/sf_reduce.hpp, include/sfhip.h)
+QUANTITY_CODES = {
+    "mdot": 0, "fx": 1, "fy": 2, "torque": 10, "power": 11, "sigma_m1": 12, "eccentricity_vector": 13,
+    "angular_momentum": 14, "mass": 15,
+}
+COMPLEX_QUANTITIES = ("sigma_m1", "eccentricity_vector")
+RATE_QUANTITIES = ("mdot", "fx", "fy", "torque", "power")
+DIAGNOSTICS_PER_LAUNCH = 8
+
 
 class HipBackend:
     """The product backend: libsfhip.so kernels on torch device arrays."""
@@ -140,6 +149,7 @@ class PatchBase:
                 self.conserved0 = xp.zeros(primitive.shape)
                 self.wavespeeds = xp.zeros(primitive.shape[:2])
         self._coords = None
+        self._reduce_workspace = None
 
     @property
     def primitive(self):
@@ -156,6 +166,23 @@ class PatchBase:
                 y1 = self.yr - 0.5 * self.mesh.dy
                 self._coords = (self.xp.linspace(x0, x1, ni)[:, None], self.xp.linspace(y0, y1, nj)[None, :])
         return self._coords
+
+    def reduce_diagnostics(self, masses, spec, num_diagnostics, sums):
+        """Launch the fused diagnostics reduction of this patch (`spec`, `sums` on its device)."""
+        ni, nj = self.shape
+        if self._reduce_workspace is None:
+            n = self.lib.reductions_workspace_len(ni, nj)
+            self._reduce_workspace = self.xp.zeros(n)
+        x, y = self.cell_center_coordinate_arrays
+        m1, m2 = masses
+        self.lib_reductions[self.shape](
+            *self._extent(), *m1.kernel_args(), *m2.kernel_args(), *self._reductions_args(),
+            self.primitive1, x, y, num_diagnostics, spec, self._reduce_workspace.numel(), self._reduce_workspace,
+            sums,
+        )
+
+    def _reductions_args(self):
+        return ()
 
     def stage_time(self, rk_param, dt):
         """Time after a stage; the reference's expression, literally (cbdiso_2d.py:239)."""
@@ -304,6 +331,76 @@ class SolverBase:
         if self._mass_cache[0] != time:
             self._mass_cache = (time, self._physics.point_masses(time))
         return self._mass_cache[1]
+
+    # ----------------------------------------------------------- diagnostics
+    def reductions(self):
+        """
+        Time-series reductions of the solution (reference: cbdiso_2d.py:370-503,
+        cbdgam_2d.py:341-443): one entry per ``physics.diagnostics`` item, a float
+        (``time`` in units of the setup's reference time scale, or a real sum times
+        dx*dy) or a complex number (``sigma_m1``, ``eccentricity_vector``).
+
+        The reference builds four full-size source-term arrays per patch and one
+        temporary per diagnostic; here each patch makes one fused pass per 8
+        diagnostics on the device (``sfhip_cbd*_2d_reductions``) and returns 16
+        doubles.  Patches are added in global patch order, then scaled by dx*dy,
+        as the reference does (:494-499).
+        """
+        diagnostics = self._physics.diagnostics
+        work = [(k, d) for k, d in enumerate(diagnostics) if d.quantity != "time"]
+        rows = [self._diagnostic_spec(d) for _, d in work]
+        per_patch = np.zeros([len(self.patches), len(work), 2])
+        if work:
+            torch = self._torch()
+            pending = []
+            for p in self.patches:
+                masses = self.point_masses(p.time)
+                with p.execution_context:
+                    spec = p.xp.array(np.array(rows, dtype=float))
+                    sums = p.xp.zeros(2 * len(work))
+                    for lo in range(0, len(work), DIAGNOSTICS_PER_LAUNCH):
+                        n = min(DIAGNOSTICS_PER_LAUNCH, len(work) - lo)
+                        p.reduce_diagnostics(masses, spec[lo:], n, sums[2 * lo:])
+                    pending.append(sums)
+            for n, sums in enumerate(pending):  # all patches launched before the first blocking read
+                per_patch[n] = to_host(sums).reshape(len(work), 2)
+            del torch
+        gathered = np.concatenate(self.comm.gather_arrays(per_patch), axis=0)  # global patch order
+        da = self.mesh.dx * self.mesh.dy
+        result = [None] * len(diagnostics)
+        for k, d in enumerate(diagnostics):
+            if d.quantity == "time":
+                result[k] = self.time / self.setup.reference_time_scale
+        for n, (k, d) in enumerate(work):
+            re = sum(float(v) for v in gathered[:, n, 0]) * da
+            if d.quantity in COMPLEX_QUANTITIES:
+                result[k] = complex(re, sum(float(v) for v in gathered[:, n, 1]) * da)
+            else:
+                result[k] = re
+        return result
+
+    def _diagnostic_spec(self, d):
+        """One row of the kernels' spec array for Diagnostic `d`; rejects what the reference cannot evaluate."""
+        q = d.quantity
+        if isinstance(q, str):
+            if q not in QUANTITY_CODES:
+                raise ValueError(f"unknown diagnostic quantity {q!r}")
+            code = QUANTITY_CODES[q]
+        else:
+            code = int(q)
+            if not 0 <= code < self.num_cons:
+                raise ValueError(f"conserved field index {q} out of range for {self.num_cons} fields")
+        is_rate = not isinstance(q, str) or q in RATE_QUANTITIES
+        which = 0
+        if is_rate:
+            if not (d.accretion or d.gravity):
+                raise ValueError(f"diagnostic {q!r} needs gravity=True or accretion=True")
+            if d.which_mass not in (1, 2, "both") or (q == "power" and d.which_mass == "both"):
+                raise ValueError(f"bad which_mass {d.which_mass!r} for diagnostic {q!r}")
+            which = 3 if d.which_mass == "both" else int(d.which_mass)
+        cut = d.radial_cut
+        return [code, which, float(bool(d.gravity)), float(bool(d.accretion)), 0.0 if cut is None else 1.0,
+                0.0 if cut is None else float(cut[0]), 0.0 if cut is None else float(cut[1]), 0.0]
 
     # -------------------------------------------------------------------- dt
     def maximum_wavespeed(self):

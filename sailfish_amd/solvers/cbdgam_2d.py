@@ -99,6 +99,13 @@ class Patch(PatchBase):
             self.launch_maximum_wavespeed(None)
             return self.wavespeed_max
 
+    @property
+    def lib_reductions(self):
+        return self.lib.sfhip_cbdgam_2d_reductions
+
+    def _reductions_args(self):
+        return (int(self.physics.constant_softening), self.physics.gamma_law_index)
+
     def launch_maximum_wavespeed(self, masses):
         gamma = self.physics.gamma_law_index
         if self.fused:

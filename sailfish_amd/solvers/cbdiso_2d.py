@@ -97,6 +97,10 @@ class Patch(PatchBase):
             self.launch_maximum_wavespeed((m1, m2))
             return self.wavespeed_max
 
+    @property
+    def lib_reductions(self):
+        return self.lib.sfhip_cbdiso_2d_reductions
+
     # ---- launches used by the Solver ---------------------------------------
     def launch_maximum_wavespeed(self, masses):
         m1, m2 = masses

@@ -28,6 +28,10 @@ Fixtures:
   gam_cooling_48.npz    gamma-law with cooling 1e-2, 48^2, 10 steps
   gam_explosion_64.npz  gamma-law explosion 64^2, 20 steps
 Each solver fixture stores: initial primitive, final primitive, dt[], time[].
+  iso_reductions_64_p2.npz, gam_reductions_48.npz
+                        Solver.reductions() of the reference after 12 steps, for a list of
+                        diagnostics covering every quantity / mass / term / radial-cut branch:
+                        the state (solution, time), the list (JSON) and the values (complex128).
 """
 import os
 import sys
@@ -87,6 +91,56 @@ def run_reference(SetupBase, make_solver, setup_name, resolution, steps, model=N
                 cfl=np.array(cfl), resolution=np.array(resolution), num_patches=np.array(num_patches))
 
 
+ISO_DIAGNOSTICS = [
+    dict(quantity="time"),
+    dict(quantity="mdot", which_mass=1, accretion=True),
+    dict(quantity="mdot", which_mass=2, accretion=True),
+    dict(quantity="mdot", which_mass="both", accretion=True, radial_cut=(0.0, 0.6)),
+    dict(quantity="torque", which_mass="both", gravity=True),
+    dict(quantity="torque", which_mass=1, accretion=True),
+    dict(quantity="torque", which_mass="both", gravity=True, radial_cut=(1.0, 2.0)),
+    dict(quantity="fx", which_mass=1, gravity=True),
+    dict(quantity="fy", which_mass=2, gravity=True),
+    dict(quantity="power", which_mass=1, gravity=True),
+    dict(quantity="power", which_mass=2, accretion=True),
+    dict(quantity="sigma_m1"),
+    dict(quantity="sigma_m1", radial_cut=(1.0, 2.5)),
+    dict(quantity="eccentricity_vector", radial_cut=(1.5, 2.5)),
+    dict(quantity="angular_momentum"),
+    dict(quantity="mass"),
+    dict(quantity="mass", radial_cut=(0.5, 2.0)),
+]
+GAM_DIAGNOSTICS = [
+    dict(quantity="time"),
+    dict(quantity="mdot", which_mass=1, accretion=True),
+    dict(quantity="mdot", which_mass=2, accretion=True),
+    dict(quantity="torque", which_mass="both", gravity=True),
+    dict(quantity="torque", which_mass="both", accretion=True, radial_cut=(0.0, 1.0)),
+    dict(quantity=3, which_mass="both", gravity=True),
+    dict(quantity=3, which_mass=2, accretion=True),
+    dict(quantity="sigma_m1"),
+    dict(quantity="eccentricity_vector", radial_cut=(1.5, 2.5)),
+]
+
+
+def run_reductions(SetupBase, make_solver, resolution, steps, diagnostics, model=None, num_patches=1):
+    import json
+
+    setup = SetupBase.find_setup_class("circumbinary-disk")(**(model or {}))
+    mesh = setup.mesh(resolution)
+    physics = dict(setup.physics)
+    physics["diagnostics"] = diagnostics
+    solver = make_solver(setup.solver, physics, {}, setup=setup, mesh=mesh, time=setup.start_time, solution=None,
+                         num_patches=num_patches, mode="cpu")
+    for _ in range(steps):
+        dt = mesh.min_spacing(solver.time) / solver.maximum_wavespeed() * solver.recommended_cfl
+        solver.advance(dt)
+    values = np.array(solver.reductions(), dtype=np.complex128)
+    return dict(solution=solver.solution.copy(), time=np.array(solver.time), values=values,
+                diagnostics=np.array(json.dumps(diagnostics)), resolution=np.array(resolution),
+                num_patches=np.array(num_patches), model=np.array(json.dumps(model or {})))
+
+
 def kepler_fixture(SetupBase):
     rows = []
     times = np.concatenate([np.linspace(0.0, 13.0, 40), [0.1, 1e-3, 100.7, 6.283185307179586, 31.4, 1e3, 2.5, 7.7, 19.9, 50.0]])
@@ -113,9 +167,16 @@ def main():
         "gam_cooling_48": run("circumbinary-disk", 48, 10, model=dict(eos="gamma-law", cooling_coefficient=1e-2)),
         "gam_explosion_64": run("cylindrical-explosion", 64, 20, model=dict(eos="gamma-law")),
     }
+    out["iso_reductions_64_p2"] = run_reductions(SetupBase, make_solver, 64, 12, ISO_DIAGNOSTICS,
+                                                 model=dict(eccentricity=0.2, mass_ratio=0.5, domain_radius=3.0, sink_radius=0.1),
+                                                 num_patches=2)
+    out["gam_reductions_48"] = run_reductions(SetupBase, make_solver, 48, 12, GAM_DIAGNOSTICS,
+                                              model=dict(eos="gamma-law", constant_softening=False, domain_radius=3.0, mass_ratio=0.4, eccentricity=0.1,
+                                                         sink_radius=0.1))
     for name, data in out.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
-        print(name, data["final"].shape, "t_end", data["time"][-1])
+        print(name, data["final"].shape if "final" in data else data["values"][:3],
+              "t_end", data["time"][-1] if data["time"].ndim else float(data["time"]))
     np.savez_compressed(os.path.join(HERE, "kepler.npz"), rows=kepler_fixture(SetupBase))
     # one-patch == four-patch bitwise for the power-of-two mesh (recorded, then relied upon by tests)
     one = run("circumbinary-disk", 128, 20, num_patches=1)

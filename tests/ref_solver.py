@@ -144,3 +144,116 @@ class OracleSolver:
                 self._call("primitive_to_conserved", p.shape, p.primitive1, p.conserved0, self.physics.gamma_law_index)
         for a in {1: [0.0], 2: [0.0, 0.5], 3: [0.0, 0.75, 1.0 / 3.0]}[self.opt["rk_order"]]:
             self.advance_rk(a, dt)
+
+
+    # ------------------------------------------------------------------ diagnostics
+    def reductions(self, diagnostics):
+        """
+        Solver.reductions() of the reference, restated on numpy (cbdiso_2d.py:370-503,
+        cbdgam_2d.py:341-443): same temporaries, same order of operations, `f.sum()` per patch,
+        Python `sum` over patches, then `* da`.  `diagnostics` is a list of Diagnostic tuples.
+        """
+        da = self.mesh.dx * self.mesh.dy
+        out = []
+        per_patch = [patch_diagnostic_sums(self, p, diagnostics) for p in self.patches]
+        for k, d in enumerate(diagnostics):
+            if d.quantity == "time":
+                out.append(self.time / self.setup.reference_time_scale)
+            else:
+                out.append(sum(sums[k] for sums in per_patch) * da)
+        return out
+
+
+def patch_source_term(solver, p, which_mass, gravity=False, accretion=False, masses=None):
+    """Patch.point_mass_source_term (cbdiso_2d.py:105-137, cbdgam_2d.py:104-143) on the CPU kernels."""
+    m1, m2 = masses or solver.physics.point_masses(p.time)
+    rate = np.zeros_like(p.primitive1)
+
+    def scaled(m):
+        return (m.position_x, m.position_y, m.velocity_x, m.velocity_y, m.mass * gravity, m.softening_length,
+                m.sink_rate * accretion, m.sink_radius, m.sink_model.value)
+
+    if solver.kind == "cbdiso_2d":
+        solver._call("point_mass_source_term", p.shape, *p.extent(), *scaled((m1, m2)[which_mass - 1]),
+                     p.primitive1, rate)
+    else:
+        solver._call("point_mass_source_term", p.shape, *p.extent(), *scaled(m1), *scaled(m2), which_mass,
+                     p.primitive1, rate, int(solver.physics.constant_softening), solver.physics.gamma_law_index)
+    return rate[NG:-NG, NG:-NG]
+
+
+def patch_diagnostic_sums(solver, p, diagnostics, masses=None, coords=None, absolute=False):
+    """One patch's `f.sum()` for every diagnostic (None for "time"); get_field of the reference, literally."""
+    mesh = solver.mesh
+    ni, nj = p.shape
+    # Patch.cell_center_coordinate_arrays (cbdiso_2d.py:82-89, 96-103)
+    if coords is None:
+        x = np.linspace(p.xl + 0.5 * mesh.dx, p.xr - 0.5 * mesh.dx, ni)[:, None]
+        y = np.linspace(p.yl + 0.5 * mesh.dy, p.yr - 0.5 * mesh.dy, nj)[None, :]
+    else:
+        x, y = coords[0].reshape(-1, 1), coords[1].reshape(1, -1)
+    m1, m2 = masses or solver.physics.point_masses(p.time)
+    acc = [patch_source_term(solver, p, w, accretion=True, masses=(m1, m2)) for w in (1, 2)]
+    grv = [patch_source_term(solver, p, w, gravity=True, masses=(m1, m2)) for w in (1, 2)]
+    prim = p.primitive1[NG:-NG, NG:-NG]
+    r = (x**2 + y**2) ** 0.5
+
+    def get_field(quantity, cut, mass, gravity, accretion):
+        def apply_radial_cut(f):
+            if cut is not None:
+                r0, r1 = cut
+                return f * (r0 < r) * (r < r1)
+            return f
+
+        if quantity == "mdot":
+            return get_field(0, cut, mass, gravity, accretion)
+        if quantity == "fx":
+            return get_field(1, cut, mass, gravity, accretion)
+        if quantity == "fy":
+            return get_field(2, cut, mass, gravity, accretion)
+        if quantity == "torque":
+            fx = get_field(1, cut, mass, gravity, accretion)
+            fy = get_field(2, cut, mass, gravity, accretion)
+            return x * fy - y * fx
+        if quantity == "sigma_m1":
+            sigma = apply_radial_cut(prim[..., 0])
+            return sigma * (x / r + 1.0j * (y / r))
+        if quantity == "eccentricity_vector":
+            sigma = apply_radial_cut(prim[..., 0])
+            vx = apply_radial_cut(prim[..., 1])
+            vy = apply_radial_cut(prim[..., 2])
+            GM = 1.0
+            v_dot_v = vx * vx + vy * vy
+            v_dot_r = vx * x + vy * y
+            ex = (v_dot_v * x - v_dot_r * vx) / GM - x / r
+            ey = (v_dot_v * y - v_dot_r * vy) / GM - y / r
+            return sigma * (ex + 1.0j * ey)
+        if quantity == "angular_momentum":
+            sigma = apply_radial_cut(prim[..., 0])
+            vx = apply_radial_cut(prim[..., 1])
+            vy = apply_radial_cut(prim[..., 2])
+            return sigma * (x * vy - y * vx)
+        if quantity == "mass":
+            return apply_radial_cut(prim[..., 0])
+        if quantity == "power":
+            fx = get_field(1, cut, mass, gravity, accretion)
+            fy = get_field(2, cut, mass, gravity, accretion)
+            if mass not in (1, 2):
+                raise ValueError("Mass option for 'power' must be 1 or 2.")
+            m = (m1, m2)[mass - 1]
+            return m.velocity_x * fx + m.velocity_y * fy
+        udots = acc if accretion else grv
+        if mass == "both":
+            f = udots[0][..., quantity] + udots[1][..., quantity]
+        else:
+            f = udots[mass - 1][..., quantity]
+        return apply_radial_cut(f)
+
+    sums = []
+    for d in diagnostics:
+        if d.quantity == "time":
+            sums.append(None)
+        else:
+            f = get_field(d.quantity, d.radial_cut, d.which_mass, d.gravity, d.accretion)
+            sums.append(np.abs(f).sum() if absolute else f.sum())
+    return sums

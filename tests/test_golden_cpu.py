@@ -78,3 +78,30 @@ def test_vectorised_initial_data_equals_per_point_loop(eos, n):
         assert np.array_equal(fast, slow)
     else:  # numpy's vector pow/exp may differ from libm in the last place (documented in setups.py)
         assert np.allclose(fast, slow, rtol=1e-14, atol=0)
+
+
+def _load_reductions(name):
+    import json
+
+    from sailfish_amd.physics.circumbinary import Diagnostic
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    diagnostics = []
+    for d in json.loads(str(g["diagnostics"])):
+        if d.get("radial_cut") is not None:
+            d["radial_cut"] = tuple(d["radial_cut"])
+        diagnostics.append(Diagnostic(**d))
+    return g, diagnostics, json.loads(str(g["model"]))
+
+
+@pytest.mark.parametrize("name", ["iso_reductions_64_p2", "gam_reductions_48"])
+def test_oracle_reductions_reproduce_reference_bitwise(name):
+    """tests/ref_solver.py's restatement of Solver.reductions() (numpy + oracle source-term kernels) against the
+    values the reference itself produced for the same state (tests/golden/generate.py: run_reductions)."""
+    g, diagnostics, model = _load_reductions(name)
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(int(g["resolution"]))
+    s = ref_solver.OracleSolver(setup, mesh, time=float(g["time"]), num_patches=int(g["num_patches"]),
+                                solution=g["solution"])
+    got = np.array(s.reductions(diagnostics), dtype=np.complex128)
+    assert np.array_equal(got, g["values"])

@@ -1,0 +1,82 @@
+"""
+GPU parity of the fused diagnostics reductions (sfhip_cbd{iso,gam}_2d_reductions via
+Solver.reductions) against (a) the values the reference itself produced (tests/golden,
+generate.py: run_reductions) and (b) the numpy restatement on the CPU oracle for other
+decompositions.  Floating-point sums in a different association order: the bar is
+1e-12 of the sum of magnitudes of the integrand (the condition-independent scale),
+written per diagnostic below.
+"""
+import numpy as np
+import pytest
+
+import ref_solver
+from sailfish_amd.physics.circumbinary import Diagnostic
+from sailfish_amd.setups import make_setup
+from sailfish_amd.solvers import make_solver
+from test_golden_cpu import _load_reductions
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def magnitude_scale(setup, mesh, g, diagnostics, num_patches):
+    """Sum of |integrand| dx dy per diagnostic, from the oracle: the scale rounding errors are relative to."""
+    s = ref_solver.OracleSolver(setup, mesh, time=float(g["time"]), num_patches=num_patches, solution=g["solution"])
+    scales = []
+    for d in diagnostics:
+        if d.quantity == "time":
+            scales.append(1.0)
+            continue
+        total = 0.0
+        for p in s.patches:
+            total += ref_solver.patch_diagnostic_sums(s, p, [d], absolute=True)[0]
+        scales.append(max(total * mesh.dx * mesh.dy, 1e-300))
+    return np.array(scales)
+
+
+@pytest.mark.parametrize("name", ["iso_reductions_64_p2", "gam_reductions_48"])
+@pytest.mark.parametrize("num_patches", [None, 1, 3])
+def test_reductions_match_reference_values(name, num_patches):
+    g, diagnostics, model = _load_reductions(name)
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(int(g["resolution"]))
+    num_patches = num_patches or int(g["num_patches"])
+    physics = dict(setup.physics, diagnostics=diagnostics)
+    s = make_solver(setup.solver, physics, {}, setup=setup, mesh=mesh, time=float(g["time"]),
+                    solution=g["solution"], num_patches=num_patches, mode="hip")
+    got = np.array(s.reductions(), dtype=np.complex128)
+    scale = magnitude_scale(setup, mesh, g, diagnostics, num_patches)
+    err = np.abs(got - g["values"]) / scale
+    assert err.max() <= TOL, (err, got, g["values"])
+    # deterministic: the same state reduces to the same bits
+    assert np.array_equal(got, np.array(s.reductions(), dtype=np.complex128))
+
+
+def test_reductions_full_size_properties():
+    """At the bench size (4096^2) the oracle is too slow: check size-independent properties instead.
+    mass with complementary radial cuts adds up to the uncut mass; 'both' == mass 1 + mass 2;
+    torque of a gravity term equals what fx, fy give on a uniform-moment-arm-free identity is not
+    available, so torque is checked by decomposition invariance (1 patch vs 4 patches)."""
+    setup = make_setup("circumbinary-disk")
+    mesh = setup.mesh(4096)
+    diagnostics = [
+        Diagnostic("mass"), Diagnostic("mass", radial_cut=(0.0, 5.0)), Diagnostic("mass", radial_cut=(5.0, 1e9)),
+        Diagnostic("mdot", accretion=True, which_mass="both"), Diagnostic("mdot", accretion=True, which_mass=1),
+        Diagnostic("mdot", accretion=True, which_mass=2),
+        Diagnostic("torque", gravity=True, which_mass="both"), Diagnostic("torque", gravity=True, which_mass=1),
+        Diagnostic("torque", gravity=True, which_mass=2), Diagnostic("angular_momentum"),
+    ]
+    physics = dict(setup.physics, diagnostics=diagnostics)
+    results = []
+    for num_patches in (1, 4):
+        s = make_solver(setup.solver, physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=num_patches,
+                        mode="hip")
+        s.step(0.3)
+        results.append(np.array(s.reductions()))
+    one, four = results
+    assert np.allclose(one, four, rtol=1e-11, atol=1e-13)
+    m, m_in, m_out, md, md1, md2, tq, tq1, tq2, lz = one
+    assert abs(m - (m_in + m_out)) <= 1e-12 * m      # r == 5.0 exactly is hit by no zone centre
+    assert abs(md - (md1 + md2)) <= 1e-12 * (abs(md1) + abs(md2))
+    assert abs(tq - (tq1 + tq2)) <= 1e-9 * (abs(tq1) + abs(tq2))
+    assert md1 < 0.0 and md2 < 0.0 and lz > 0.0 and abs(m - 24.0**2) < 1.0

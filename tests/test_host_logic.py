@@ -212,3 +212,44 @@ def test_step_redoes_stage_when_filtered_wavespeed_is_below_floor():
     b.advance(dt_b)
     assert dt_a == dt_b and a.time == b.time
     assert np.array_equal(a.solution, b.solution)
+
+
+@pytest.mark.parametrize("name", ["iso_reductions_64_p2", "gam_reductions_48"])
+def test_solver_reductions_reproduce_reference_bitwise(name):
+    """Solver.reductions() host logic (spec encoding, batching by 8, patch order, dx*dy, complex results) with
+    the oracle backend == the values the reference produced for the same state."""
+    from oracle_backend import OracleBackend
+    from sailfish_amd.setups import make_setup
+    from sailfish_amd.solvers import make_solver
+    from test_golden_cpu import _load_reductions
+
+    g, diagnostics, model = _load_reductions(name)
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(int(g["resolution"]))
+    physics = dict(setup.physics)
+    physics["diagnostics"] = diagnostics
+    s = make_solver(setup.solver, physics, {}, setup=setup, mesh=mesh, time=float(g["time"]),
+                    solution=g["solution"], num_patches=int(g["num_patches"]), backend=OracleBackend(),
+                    distributed=False)
+    got = s.reductions()
+    assert [type(v) for v in got] == [complex if d.quantity in ("sigma_m1", "eccentricity_vector") else float
+                                      for d in diagnostics]
+    assert np.array_equal(np.array(got, dtype=np.complex128), g["values"])
+
+
+def test_reductions_reject_what_the_reference_cannot_evaluate():
+    from oracle_backend import OracleBackend
+    from sailfish_amd.physics.circumbinary import Diagnostic
+    from sailfish_amd.setups import make_setup
+    from sailfish_amd.solvers import make_solver
+
+    setup = make_setup("circumbinary-disk")
+    mesh = setup.mesh(16)
+    for bad in (Diagnostic("mdot", which_mass=1), Diagnostic("power", gravity=True, which_mass="both"),
+                Diagnostic("nonsense"), Diagnostic(3, gravity=True, which_mass=1),
+                Diagnostic("torque", gravity=True, which_mass=3)):
+        physics = dict(setup.physics, diagnostics=[bad])
+        s = make_solver(setup.solver, physics, {}, setup=setup, mesh=mesh, time=0.0, backend=OracleBackend(),
+                        distributed=False)
+        with pytest.raises(ValueError):
+            s.reductions()
