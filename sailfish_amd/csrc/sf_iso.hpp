@@ -35,6 +35,9 @@ struct IsoParams {
     double cs2, mach2;
     double cs2_uniform, cs_uniform, inv_mach2; // used when !eos_local / eos_local
     double nu, a, dt, vmax, dfloor;
+    // uniform values the kernel would otherwise form with vector instructions (there is no scalar fp64
+    // unit) and keep in vector registers: evaluated on the host, they arrive in SGPRs
+    double half_nu, half_inv_dx, half_inv_dy, one_minus_a, sink_reach2[2];
     // fusion / boundary flags
     int clamp_ilo, clamp_ihi;   // patch touches the domain edge in i: clamp instead of reading guards
     int clamp_j;                // outflow in j by clamping (always true for slab decomposition)
@@ -71,6 +74,17 @@ __device__ __forceinline__ double iso_cs2(const IsoParams &P, const Mass *m, dou
     if (P.eos == 1) return P.cs2;
     if (P.eos == 2) return -iso_potential(m, x, y) / P.mach2;
     return 1.0;
+}
+
+// The exact wavespeed of one zone as an out-of-line call: the fused epilogue reaches it for a
+// handful of zones per launch, and inlined its IEEE sqrt/divide expansions would raise the register
+// allocation of the whole stage kernel (3 -> 2 waves per SIMD).
+__device__ __attribute__((noinline)) double iso_exact_speed(const IsoParams *Pk, double x, double y, double vx, double vy)
+{
+#pragma clang fp contract(off)
+    // few arguments on purpose (each one is a register pair the call site has to free); the rest is
+    // read from the parameter block here
+    return max_speed(vx, vy, iso_cs2(*Pk, Pk->mw, x, y));
 }
 
 // ---- fast pieces: the stage kernel (within ~1 ulp of the above) -------------
@@ -113,48 +127,63 @@ __device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, dou
 }
 
 // One point mass: gravity + sink, cbdiso_2d.c:97-175.  Accumulates into dc.
-// `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed.
-__device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double ddy, double cy, double dt,
-                                                const double *prim, double *dc)
+// `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed; `sink_reach2` =
+// (4 r_sink)^2 + rs^2.  `cold` points at the same mass in memory: what only the sink branch needs
+// (a handful of waves per launch) is loaded there, on demand, instead of occupying SGPRs throughout.
+__device__ __forceinline__ double iso_mass_source(double mx, double mmass, double sink_reach2, const Mass *cold,
+                                                  double x1, double ddy, double cy, double dt,
+                                                  const double *prim, double *dc)
 {
 #pragma clang fp contract(fast)
     double sigma = prim[0];
-    double ddx = x1 - m.x;
+    double ddx = x1 - mx;
     double r2s = ddx * ddx + cy;
-    double y = fast_rsqrt(r2s);
-    double fnum = sigma * m.mass * (y * y * y) * dt; // pow(r^2 + rs^2, -1.5) of the reference
+    const double y = fast_rsqrt(r2s); // 1/sqrt(r^2 + rs^2): returned, the wavespeed epilogue reuses it
+    double fnum = sigma * mmass * (y * y * y) * dt; // pow(r^2 + rs^2, -1.5) of the reference
     dc[1] -= fnum * ddx;
     dc[2] -= fnum * ddy;
-    double rs4 = 4.0 * m.sink_radius;
-    if (r2s < rs4 * rs4 + m.rsoft * m.rsoft) { // superset of dr < 4 r_sink; exact test inside
+    if (r2s < sink_reach2) { // superset of dr < 4 r_sink; exact test inside
+        const double sink_radius = cold->sink_radius;
+        double rs4 = 4.0 * sink_radius;
         double r2 = ddx * ddx + ddy * ddy;
         double dr = sqrt(r2);
         if (dr < rs4) { // lazily evaluated like the C ternary: r_sink == 0 never divides
-            double q = dr / m.sink_radius;
+            const double mvx = cold->vx, mvy = cold->vy;
+            const int sink_model = cold->sink_model;
+            double q = dr / sink_radius;
             double q2 = q * q;
-            double rate = m.sink_rate * exp(-(q2 * q2));
+            double rate = cold->sink_rate * exp(-(q2 * q2));
             double mdot = 0.0;
             if (rate > 0.0) mdot = -rate * sigma;
             else if (rate < 0.0) mdot = -rate;
-            if (m.sink_model == 1) {
+            if (sink_model == 1) {
                 dc[0] += dt * mdot;
                 dc[1] += dt * mdot * prim[1];
                 dc[2] += dt * mdot * prim[2];
-            } else if (m.sink_model == 2) {
+            } else if (sink_model == 2) {
                 double rinv = 1.0 / (dr + 1e-12);
                 double rhx = ddx * rinv;
                 double rhy = ddy * rinv;
-                double dv = (prim[1] - m.vx) * rhx + (prim[2] - m.vy) * rhy;
-                double vxs = dv * rhx + m.vx;
-                double vys = dv * rhy + m.vy;
+                double dv = (prim[1] - mvx) * rhx + (prim[2] - mvy) * rhy;
+                double vxs = dv * rhx + mvx;
+                double vys = dv * rhy + mvy;
                 dc[0] += dt * mdot;
                 dc[1] += dt * mdot * vxs;
                 dc[2] += dt * mdot * vys;
-            } else if (m.sink_model == 3) {
+            } else if (sink_model == 3) {
                 dc[0] += dt * mdot;
             }
         }
     }
+    return y;
+}
+
+// convenience form for the small kernels (everything from the by-value struct)
+__device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double ddy, double cy, double dt,
+                                                const double *prim, double *dc)
+{
+    double rs4 = 4.0 * m.sink_radius;
+    iso_mass_source(m.x, m.mass, rs4 * rs4 + m.rsoft * m.rsoft, &m, x1, ddy, cy, dt, prim, dc);
 }
 
 // Keplerian buffer, cbdiso_2d.c:213-246
@@ -181,8 +210,11 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 // grid: 1-D, 256 threads = 4 waves; wave w of the grid owns column strip
 // (w % nstrips) and row chunk (w / nstrips).
 // ---------------------------------------------------------------------------
-template <bool WS, bool UN>
-__global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
+// WS: 0 no wavespeed epilogue; 1 epilogue with its own masses P.mw (output time != stage time: RK1, RK3);
+//     2 epilogue when P.mw == P.m bit for bit (last stage of RK2): the softened distances of the
+//     source terms are reused for the sound-speed estimate.
+template <int WS, bool UN>
+__global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
@@ -194,6 +226,11 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return; // whole wave leaves together
     if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
+    // The same parameter block, addressed through a pointer whose origin the optimiser cannot see:
+    // loads through it stay inside the rarely taken branches that need them (sink interior, exact
+    // wavespeed) instead of being hoisted into SGPRs that the whole march would then have to spill.
+    const IsoParams *Pk = (const IsoParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Pk));
 
     const int ni = P.ni, nj = P.nj;
     const long sj = 3, si = 3L * (nj + 2 * NG);
@@ -216,7 +253,7 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
     const int rlo = P.clamp_ilo ? NG : 0;
     const int rhi = P.clamp_ihi ? ni + NG - 1 : ni + 2 * NG - 1;
     const bool visc = P.nu > 0.0;
-    const double hnu = 0.5 * P.nu;
+    const double hnu = P.half_nu;
     // lane-invariant pieces of the distances to the two masses
     const double dyc0 = yc - P.m[0].y, dyc1 = yc - P.m[1].y;
     const double cyc0 = dyc0 * dyc0 + P.m[0].rsoft * P.m[0].rsoft;
@@ -224,13 +261,14 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
     const double cyf0 = (yf - P.m[0].y) * (yf - P.m[0].y) + P.m[0].rsoft * P.m[0].rsoft;
     const double cyf1 = (yf - P.m[1].y) * (yf - P.m[1].y) + P.m[1].rsoft * P.m[1].rsoft;
     const double yc2 = yc * yc;
+    const double reach0 = P.sink_reach2[0], reach1 = P.sink_reach2[1]; // (4 r_sink)^2 + rs^2
     double cyw0 = 0, cyw1 = 0;
-    if (WS) {
+    if (WS == 1) {
         cyw0 = (yc - P.mw[0].y) * (yc - P.mw[0].y) + P.mw[0].rsoft * P.mw[0].rsoft;
         cyw1 = (yc - P.mw[1].y) * (yc - P.mw[1].y) + P.mw[1].rsoft * P.mw[1].rsoft;
     }
     const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
-    const double hidx = 0.5 * P.inv_dx, hidy = 0.5 * P.inv_dy; // slopes are carried doubled
+    const double hidx = P.half_inv_dx, hidy = P.half_inv_dy; // slopes are carried doubled
     // 0.25 is not an inline constant on gfx9: as a literal it forces v_mov + v_fmac (VOP2) for every
     // p +- 0.25 g.  Held opaquely in an SGPR pair it is a plain operand of a 3-address v_fma_f64.
     double quarter = 0.25;
@@ -245,7 +283,7 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
 
     // software prefetch: row r+1 (and the u^n source of the row updated next) is requested one
     // iteration ahead so its HBM latency overlaps this iteration's arithmetic
-    double pn[3], un[3] = {0, 0, 0}, unn[3] = {0, 0, 0};
+    double pn[3], un[3] = {0, 0, 0};
     {
         int rl = I0 - 2 < rlo ? rlo : (I0 - 2 > rhi ? rhi : I0 - 2);
         const double *src = prd + rl * si + col;
@@ -256,16 +294,11 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
 
     for (int r = I0 - 2; r <= I1 + 1; ++r) {
         pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2];
-        un[0] = unn[0]; un[1] = unn[1]; un[2] = unn[2];
         if (r < I1 + 1) {
             int rn = r + 1;
             int rl = rn < rlo ? rlo : (rn > rhi ? rhi : rn);
             const double *src = prd + rl * si + col;
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
-            if (want_un && rn - 2 >= I0) {
-                const double *us = unsrc + (long)(rn - 2) * si + ucol;
-                unn[0] = us[0]; unn[1] = us[1]; unn[2] = us[2];
-            }
         }
 
         // y-slopes of row r from the neighbouring lanes
@@ -303,6 +336,13 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
                     F[2] -= hnu * (txy + pb[0] * sxy);
                 }
             }
+            if (want_un && r - 2 >= I0) {
+                // u^n of the row updated at the bottom of this iteration, requested here: the y-face and
+                // source-term arithmetic in between (~250 instructions x 3 waves) covers the latency, and
+                // the three values are not live across the x-face block
+                const double *us = unsrc + (long)(r - 2) * si + ucol;
+                un[0] = us[0]; un[1] = us[1]; un[2] = us[2];
+            }
             if (r - 1 >= I0 && r - 1 < I1) {
                 // y-face below this lane's zone in row r-1 (cbdiso_2d.c:543-546, 562-563, 583-586)
                 double pmy[3], ppy[3], G[3], c2, cs;
@@ -327,8 +367,8 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
                 double u[3] = {pa[0], pa[1] * pa[0], pa[2] * pa[0]};
                 double dc[3] = {0.0, 0.0, 0.0};
                 iso_buffer(P, xc, yc, yc2, u, dc);
-                iso_mass_source(P.m[0], xc, dyc0, cyc0, P.dt, pa, dc);
-                iso_mass_source(P.m[1], xc, dyc1, cyc1, P.dt, pa, dc);
+                const double y0 = iso_mass_source(P.m[0].x, P.m[0].mass, reach0, &Pk->m[0], xc, dyc0, cyc0, P.dt, pa, dc);
+                const double y1 = iso_mass_source(P.m[1].x, P.m[1].mass, reach1, &Pk->m[1], xc, dyc1, cyc1, P.dt, pa, dc);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     dc[q] -= ((F[q] - Fp[q]) * P.inv_dx + dGp[q] * P.inv_dy) * P.dt;
@@ -338,7 +378,7 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
                 if (want_un) {
                     double un0 = un[0], un1 = un[1], un2 = un[2];
                     if (P.un_mode == 2) { un1 *= un0; un2 *= un0; } // u^n = p2c(p^n), cbdiso_2d.c:285-298
-                    const double b = 1.0 - P.a;
+                    const double b = P.one_minus_a;
                     u[0] = b * u[0] + P.a * un0;
                     u[1] = b * u[1] + P.a * un1;
                     u[2] = b * u[2] + P.a * un2;
@@ -357,11 +397,21 @@ __global__ __launch_bounds__(256, (WS || UN) ? 2 : 3) void iso_stage_kernel(
                         // so the reduced value is bit-identical to cbdiso_2d_wavespeed + max.
                         double vm = __builtin_fmax(fabs(vx), fabs(vy));
                         double c2e, cse;
-                        iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
+                        if (WS == 2) {
+                            if (!P.eos_local) cse = P.cs_uniform;
+                            else {
+                                c2e = 0.0;
+                                if (P.m[0].mass > 0.0) c2e += P.m[0].mass * y0;
+                                if (P.m[1].mass > 0.0) c2e += P.m[1].mass * y1;
+                                c2e *= P.inv_mach2;
+                                cse = sqrt_from_rsqrt(c2e, fast_rsqrt(c2e));
+                            }
+                        } else {
+                            iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
+                        }
                         if ((vm + cse) * (1.0 + 1e-9) >= athr) {
-#pragma clang fp contract(off)
-                            double c2 = iso_cs2(P, P.mw, xc, yc);
-                            amax = max2(amax, max_speed(vx, vy, c2));
+                            double sp = iso_exact_speed(Pk, xc, yc, vx, vy);
+                            amax = max2(amax, sp);
                             athr = max2(athr, amax);
                         }
                     }

@@ -93,8 +93,15 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = 4;
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    auto kernel = P.want_wavespeed ? (P.un_mode ? sf::iso_stage_kernel<true, true> : sf::iso_stage_kernel<true, false>)
-                                   : (P.un_mode ? sf::iso_stage_kernel<false, true> : sf::iso_stage_kernel<false, false>);
+    // epilogue masses identical to the stage's (RK2's last stage): the kernel reuses the source terms' distances
+    bool same = P.want_wavespeed != 0;
+    for (int k = 0; k < 2 && same; ++k)
+        same = memcmp(&P.m[k].x, &P.mw[k].x, sizeof(double)) == 0 && memcmp(&P.m[k].y, &P.mw[k].y, sizeof(double)) == 0 &&
+               memcmp(&P.m[k].mass, &P.mw[k].mass, sizeof(double)) == 0 &&
+               memcmp(&P.m[k].rsoft, &P.mw[k].rsoft, sizeof(double)) == 0;
+    auto kernel = !P.want_wavespeed ? (P.un_mode ? sf::iso_stage_kernel<0, true> : sf::iso_stage_kernel<0, false>)
+                  : same            ? (P.un_mode ? sf::iso_stage_kernel<2, true> : sf::iso_stage_kernel<2, false>)
+                                    : (P.un_mode ? sf::iso_stage_kernel<1, true> : sf::iso_stage_kernel<1, false>);
     hipLaunchKernelGGL(kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
     return check_launch("cbdiso_2d stage launch");
 }
@@ -151,6 +158,12 @@ void fill_iso(sf::IsoParams &P, int ni, int nj, double pxl, double pxr, double p
     P.cs_uniform = sqrt(P.cs2_uniform);
     P.inv_mach2 = 1.0 / mach2;
     P.nu = nu; P.a = a; P.dt = dt; P.vmax = vmax; P.dfloor = dfloor;
+    P.half_nu = 0.5 * nu;
+    P.half_inv_dx = 0.5 * P.inv_dx;
+    P.half_inv_dy = 0.5 * P.inv_dy;
+    P.one_minus_a = 1.0 - a;
+    P.sink_reach2[0] = 16.0 * m1.sink_radius * m1.sink_radius + m1.rsoft * m1.rsoft;
+    P.sink_reach2[1] = 16.0 * m2.sink_radius * m2.sink_radius + m2.rsoft * m2.rsoft;
     P.clamp_ilo = P.clamp_ihi = P.clamp_j = 0;
     P.un_mode = a != 0.0 ? 1 : 0;
     P.i_begin = 0; P.i_end = ni;

@@ -61,10 +61,14 @@ def simulate(solver, mesh, cfl_number=None, fold=10, new_timestep_cadence=1, max
 
 
 def run(setup_name, resolution=None, num_patches=None, mode="hip", model_parameters=None, solver_options=None,
-        cfl_number=None, fold=10, new_timestep_cadence=1, max_iterations=None, end_time=None, **solver_kwargs):
+        cfl_number=None, fold=10, new_timestep_cadence=1, max_iterations=None, end_time=None, timeseries=None,
+        **solver_kwargs):
     """
     Build setup, mesh and solver, run to completion, return (solver, reports).
-    Counterpart of ``sailfish.driver.run`` (driver.py:522-543) without events.
+    Counterpart of ``sailfish.driver.run`` (driver.py:522-543) without events,
+    except the one that is arithmetic on the solution: when `timeseries` is a
+    list, ``solver.reductions()`` is appended to it after every fold (the
+    reference's ``timeseries`` event, driver.py:498-499, at fold cadence).
     """
     setup = make_setup(setup_name, **(model_parameters or {}))
     mesh = setup.mesh(resolution or setup.default_resolution)
@@ -75,8 +79,10 @@ def run(setup_name, resolution=None, num_patches=None, mode="hip", model_paramet
     )
     if end_time is None and max_iterations is None:
         end_time = setup.default_end_time
-    reports = list(
-        simulate(solver, mesh, cfl_number, fold, new_timestep_cadence, max_iterations, end_time,
-                 setup.reference_time_scale)
-    )
+    reports = []
+    for report in simulate(solver, mesh, cfl_number, fold, new_timestep_cadence, max_iterations, end_time,
+                           setup.reference_time_scale):
+        reports.append(report)
+        if timeseries is not None:
+            timeseries.append(solver.reductions())
     return solver, reports

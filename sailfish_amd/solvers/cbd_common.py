@@ -294,6 +294,7 @@ class SolverBase:
         self._mass_cache = (None, None)
         self._wavespeed_floor = 0.0
         self._dt_dev = None
+        self._fetch_stream = None
         self.event_log = None  # bench.py sets this to a list to time every stage launch with HIP events
 
     def _patch_kwargs(self):
@@ -522,11 +523,12 @@ class SolverBase:
                 with p0.execution_context:
                     self._dt_dev = p0.xp.zeros(1)
             with p0.execution_context:
+                fetch = self._start_scalar_fetch(amax_dev)  # read-back on a side stream, not behind stage 0
                 p0.lib.sfhip_timestep[1](float(dx), float(cfl_number), amax_dev, self._dt_dev)
             self.new_iteration()
             # dt is not known on the host yet: nothing below may depend on it (stage 0 never does)
             wrote = self.advance_rk(params[0], float("nan"), 0, len(params), dt_device=self._dt_dev)
-            amax = float(amax_dev.item())  # the one device->host sync of the step, overlapped with stage 0
+            amax = fetch()  # the one device->host sync of the step; stage 0 is still running on the device
             if have_fused and amax < floor:
                 have_fused = False  # the filtered maximum is only a lower bound: recompute exactly and redo stage 0
                 continue
@@ -538,6 +540,33 @@ class SolverBase:
         for stage in range(1, len(params)):
             self.advance_rk(params[stage], dt, stage, len(params))
         return dt
+
+    def _start_scalar_fetch(self, scalar):
+        """
+        Begin copying a one-element device array to the host on a side stream, ordered after the
+        work already queued on the current stream but NOT after what is queued later; returns a
+        function that blocks until the value has arrived and returns it as a float.
+        """
+        if self.backend.mode != "hip":
+            return lambda: float(scalar.item())
+        torch = self._torch()
+        if self._fetch_stream is None:
+            self._fetch_stream = torch.cuda.Stream()
+            self._fetch_host = torch.empty(1, dtype=torch.float64).pin_memory()
+            self._fetch_done = torch.cuda.Event()
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._fetch_stream):
+            self._fetch_stream.wait_event(ready)
+            self._fetch_host.copy_(scalar, non_blocking=True)
+            self._fetch_done.record()
+        scalar.record_stream(self._fetch_stream)
+
+        def wait():
+            self._fetch_done.synchronize()
+            return float(self._fetch_host[0])
+
+        return wait
 
     def _reduce_wavespeed_device(self, recompute):
         """Max wavespeed over local patches and ranks as a device scalar; nothing here blocks the host."""

@@ -80,3 +80,17 @@ def test_reductions_full_size_properties():
     assert abs(md - (md1 + md2)) <= 1e-12 * (abs(md1) + abs(md2))
     assert abs(tq - (tq1 + tq2)) <= 1e-9 * (abs(tq1) + abs(tq2))
     assert md1 < 0.0 and md2 < 0.0 and lz > 0.0 and abs(m - 24.0**2) < 1.0
+
+
+def test_driver_run_collects_timeseries():
+    """driver.run with the setup's own 'mdots' diagnostics: one reductions() row per fold (driver.py:498-499)."""
+    from math import pi
+
+    from sailfish_amd.driver import run
+
+    series = []
+    solver, reports = run("circumbinary-disk", resolution=64, max_iterations=20, fold=10, timeseries=series,
+                          model_parameters=dict(which_diagnostics="mdots", domain_radius=3.0))
+    assert len(reports) == 2 and len(series) == 2 and len(series[0]) == 3
+    assert series[1][0] == reports[1].time / (2.0 * pi)
+    assert series[1][1] < 0.0 and series[1][2] < 0.0  # both sinks remove mass
