@@ -36,6 +36,9 @@ struct GamParams {
     int rows_per_chunk, i_begin, i_end, want_wavespeed;
     double ws_floor; // zones slower than this are not folded in (see include/sfhip.h)
     const double *dt_ptr;       // when set, the timestep is read from device memory instead of `dt`
+    // uniform values evaluated on the host so that they arrive in SGPRs (no scalar fp64 unit: formed
+    // in the kernel they would sit in vector registers for the whole march)
+    double half_inv_dx, half_inv_dy, one_minus_a, inv_buf_sd, sink_near2[2]; // sink_near2 = (4 r_sink)^2
 };
 
 // ---- exact pieces (reference-named small kernels, wavespeed/dt path) -------
@@ -179,7 +182,10 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
 
 // One point mass, cbdgam_2d.c:108-203.  `ddy`, `cy` = ddy^2 (+ rs^2 when softening is constant) per lane;
 // `eps` = specific internal energy, `h` = disk height (non-constant softening only).
-__device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double x1, double ddy, double dt,
+// `near2` = (4 r_sink)^2 from the host; `cold` addresses the same mass in memory for what only the
+// sink interior needs (loaded there, on demand, instead of occupying SGPRs throughout the march).
+__device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double near2, const Mass *cold,
+                                                     double x1, double ddy, double dt,
                                                      const double *prim, double eps, double h, double *u,
                                                      int constant_softening)
 {
@@ -193,7 +199,7 @@ __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double x1, d
     double r_soft = m.rsoft;
     double rate = 0.0;
     double dr = 0.0;
-    const bool near = r2 < rs4 * rs4;
+    const bool near = r2 < near2;
     if (!constant_softening || near) dr = sqrt(r2);
     if (!constant_softening) {
         if (dr > r_sink) r_soft = 0.5 * h;
@@ -207,7 +213,7 @@ __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double x1, d
     if (near && dr < rs4) {
         double q = dr / r_sink;
         double q2 = q * q;
-        rate = m.sink_rate * exp(-(q2 * q2));
+        rate = cold->sink_rate * exp(-(q2 * q2));
     }
     double y = fast_rsqrt(r2 + r_soft * r_soft);
     double fnum = sigma * m.mass * (y * y * y);
@@ -228,14 +234,22 @@ __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double x1, d
         } else if (m.sink_model == 2) {
             double rinv = 1.0 / (dr + 1e-12);
             double rhx = ddx * rinv, rhy = ddy * rinv;
-            double dv = (vx - m.vx) * rhx + (vy - m.vy) * rhy;
-            double vxs = dv * rhx + m.vx;
-            double vys = dv * rhy + m.vy;
+            const double mvx = cold->vx, mvy = cold->vy;
+            double dv = (vx - mvx) * rhx + (vy - mvy) * rhy;
+            double vxs = dv * rhx + mvx;
+            double vys = dv * rhy + mvy;
             u[1] += dt * mdot * vxs;
             u[2] += dt * mdot * vys;
             u[3] += dt * (mdot * eps + 0.5 * mdot * (vxs * vxs + vys * vys));
         }
     }
+}
+
+// exact wavespeed of one zone, out of line (see iso_exact_speed in sf_iso.hpp)
+__device__ __attribute__((noinline)) double gam_exact_speed(double vx, double vy, double pres, double rho, double gamma)
+{
+#pragma clang fp contract(off)
+    return max_speed(vx, vy, pres / rho * gamma);
 }
 
 // cbdgam_2d.c:238-276
@@ -250,7 +264,7 @@ __device__ __forceinline__ void gam_buffer_fast(const GamParams &P, double xc, d
         double vk2 = P.buf_mc * rinv;
         double pf = P.buf_sd * sqrt_from_rsqrt(vk2, fast_rsqrt(vk2)) * rinv; // sigma v_kep / rc
         double px = -pf * yc, py = pf * xc;
-        double en = P.buf_e0 + 0.5 * (px * px + py * py) * fast_rcp(P.buf_sd);
+        double en = P.buf_e0 + 0.5 * (px * px + py * py) * P.inv_buf_sd;
         double br = P.buf_rate_scale * (rc - P.buf_ron) * P.dt;
         u[0] -= (u[0] - P.buf_sd) * br;
         u[1] -= (u[1] - px) * br;
@@ -277,7 +291,7 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
 }
 
 template <bool WS, bool UN>
-__global__ __launch_bounds__(256) void gam_stage_kernel(
+__global__ __launch_bounds__(256, 2) void gam_stage_kernel(
     GamParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
@@ -289,6 +303,10 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return;
     if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
+    // the parameter block again, through a pointer of hidden origin: loads through it stay inside the
+    // rarely taken branches that need them (see sf_iso.hpp)
+    const GamParams *Pk = (const GamParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Pk));
 
     const int ni = P.ni, nj = P.nj;
     const long sj = 4, si = 4L * (nj + 2 * NG);
@@ -319,12 +337,12 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
     const double oyf0 = (yf - P.m[0].y) * (yf - P.m[0].y) + 1e-12, oyf1 = (yf - P.m[1].y) * (yf - P.m[1].y) + 1e-12;
     const double yc2 = yc * yc;
     const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
-    const double hidx = 0.5 * P.inv_dx, hidy = 0.5 * P.inv_dy; // slopes are carried doubled
+    const double hidx = P.half_inv_dx, hidy = P.half_inv_dy; // slopes are carried doubled
     // 0.25 is not an inline constant on gfx9 (see sf_iso.hpp): keep it as an opaque SGPR operand
     double quarter = 0.25;
     asm volatile("" : "+s"(quarter));
 
-    double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4], pn[4], un[4] = {0, 0, 0, 0}, unn[4] = {0, 0, 0, 0};
+    double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4], pn[4], un[4] = {0, 0, 0, 0};
     double gyb[4] = {0, 0, 0, 0};
     // carried from row r-2 (the lower side of the next x-face)
     double pmx[4] = {1, 0, 0, 1}, sxxa = 0, sxya = 0, csa = 1, qha = 1, nua = 0;
@@ -340,16 +358,17 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
 
     for (int r = I0 - 2; r <= I1 + 1; ++r) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { pc[q] = pn[q]; un[q] = unn[q]; }
+        for (int q = 0; q < 4; ++q) pc[q] = pn[q];
         if (r < I1 + 1) {
             int rn = r + 1;
             int rl = rn < rlo ? rlo : (rn > rhi ? rhi : rn);
             const double *src = prd + rl * si + col;
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
-            if (UN && rn - 2 >= I0) {
-                const double *us = unsrc + (long)(rn - 2) * si + ucol;
-                unn[0] = us[0]; unn[1] = us[1]; unn[2] = us[2]; unn[3] = us[3];
-            }
+        }
+        if (UN && r - 2 >= I0) {
+            // u^n of the row updated at the bottom of this iteration: the whole iteration covers its latency
+            const double *us = unsrc + (long)(r - 2) * si + ucol;
+            un[0] = us[0]; un[1] = us[1]; un[2] = us[2]; un[3] = us[3];
         }
 
         double gyc[4];
@@ -443,8 +462,8 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                 double hcc = 1.0;
                 if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast(P.m, xc, oyc0, oyc1);
                 gam_buffer_fast(P, xc, yc, yc2, u);
-                gam_mass_source_fast(P.m[0], xc, dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
-                gam_mass_source_fast(P.m[1], xc, dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_mass_source_fast(P.m[0], P.sink_near2[0], &Pk->m[0], xc, dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_mass_source_fast(P.m[1], P.sink_near2[1], &Pk->m[1], xc, dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
                 gam_cooling_fast(P, pa, eps, rinva, u);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) u[q] -= ((FL[q] - Fp[q]) * P.inv_dx + dGp[q] * P.inv_dy) * P.dt;
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                         w[1] = un[1] * un[0];
                         w[2] = un[2] * un[0];
                     }
-                    const double b = 1.0 - P.a;
+                    const double b = P.one_minus_a;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) u[q] = b * u[q] + P.a * w[q];
                 }
@@ -475,8 +494,7 @@ __global__ __launch_bounds__(256) void gam_stage_kernel(
                         double pre = pres * fast_rcp(rho) * gamma;
                         double cse = sqrt_from_rsqrt(pre, fast_rsqrt(pre));
                         if ((__builtin_fmax(fabs(vx), fabs(vy)) + cse) * (1.0 + 1e-9) >= athr) {
-#pragma clang fp contract(off)
-                            amax = max2(amax, max_speed(vx, vy, pres / rho * gamma));
+                            amax = max2(amax, gam_exact_speed(vx, vy, pres, rho, gamma));
                             athr = max2(athr, amax);
                         }
                     }

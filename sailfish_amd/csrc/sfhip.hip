@@ -201,6 +201,12 @@ void fill_gam(sf::GamParams &P, int ni, int nj, double pxl, double pxr, double p
     P.mach_ceiling_m2 = pow(mach_ceiling, -2.0);          // cbdgam_2d.c:314
     P.mach_floor_scale = 2.0 / gamma / (gamma - 1.0) * P.mach_ceiling_m2;
     P.dfloor = dfloor; P.pfloor = pfloor;
+    P.half_inv_dx = 0.5 * P.inv_dx;
+    P.half_inv_dy = 0.5 * P.inv_dy;
+    P.one_minus_a = 1.0 - a;
+    P.inv_buf_sd = bsd != 0.0 ? 1.0 / bsd : 0.0;
+    P.sink_near2[0] = 16.0 * m1.sink_radius * m1.sink_radius;
+    P.sink_near2[1] = 16.0 * m2.sink_radius * m2.sink_radius;
     P.un_mode = a != 0.0 ? 1 : 0;
     P.i_begin = 0; P.i_end = ni;
 }
