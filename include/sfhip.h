@@ -545,6 +545,91 @@ SFHIP_API int sfhip_reductions_workspace_len(
     int nj)
 ;
 
+/* ---------------------------------------------------------------------------
+ * srhd_2d -- 2-D special-relativistic hydrodynamics on a log-spherical, homologously
+ * expanding mesh (BASELINE.json configs[4]).
+ * State arrays are (ni + 4, nj, 4): two guard zones in i only, fields fastest.
+ * --------------------------------------------------------------------------- */
+
+/* The reference compiles PLM_THETA and MACH_CEILING into the kernel library
+ * (Library(..., define_macros=...), srhd_2d.py:225-233; srhd_2d.c:17-27).  Here they
+ * are library state, set once per Solver; n must be 1. */
+SFHIP_API int sfhip_srhd_2d_set_macros(
+    int n,
+    double plm_theta,
+    double mach_ceiling)
+;
+
+/* Replaces srhd_2d_primitive_to_conserved, srhd_2d.c:511-538 (caller: Patch.__init__,
+ * srhd_2d.py:127-133).  No guard zones on either array. */
+SFHIP_API int srhd_2d_primitive_to_conserved(
+    int ni,
+    int nj,
+    double *face_positions, // :: $.shape == (ni + 1,)
+    double *primitive, // :: $.shape == (ni, nj, 4)
+    double *conserved, // :: $.shape == (ni, nj, 4)
+    double polar_extent,
+    double scale_factor) // :: $ >= 0.0
+;
+
+/* Replaces srhd_2d_conserved_to_primitive, srhd_2d.c:544-575 (caller:
+ * Patch.recompute_primitive, srhd_2d.py:144-154).  Newton iteration on the pressure
+ * from the previous primitive[..., 3]; where the reference printf()s and exit(1)s
+ * (srhd_2d.c:164-184) this entry point counts the zone in the library's failure
+ * counter (sfhip_srhd_2d_failures) and carries on. */
+SFHIP_API int srhd_2d_conserved_to_primitive(
+    int ni,
+    int nj,
+    double *face_positions, // :: $.shape == (ni + 1,)
+    double *conserved1, // :: $.shape == (ni + 4, nj, 4)
+    double *conserved2, // :: $.shape == (ni + 4, nj, 4)
+    double *primitive, // :: $.shape == (ni + 4, nj, 4)
+    double polar_extent,
+    double scale_factor) // :: $ >= 0.0
+;
+
+/* Replaces srhd_2d_max_wavespeeds, srhd_2d.c:581-609 (caller: Patch.maximum_wavespeed,
+ * srhd_2d.py:179-188). */
+SFHIP_API int srhd_2d_max_wavespeeds(
+    int ni,
+    int nj,
+    double *face_positions, // :: $.shape == (ni + 1,)
+    double *primitive, // :: $.shape == (ni + 4, nj, 4)
+    double *wavespeed, // :: $.shape == (ni, nj)
+    double adot) // :: $ >= 0.0
+;
+
+/* Replaces srhd_2d_advance_rk, srhd_2d.c:616-749 (caller: Patch.advance_rk,
+ * srhd_2d.py:156-177). */
+SFHIP_API int srhd_2d_advance_rk(
+    int ni,
+    int nj,
+    double *face_positions, // :: $.shape == (ni + 1,)
+    double *conserved_rk, // :: $.shape == (ni + 4, nj, 4)
+    double *primitive_rd, // :: $.shape == (ni + 4, nj, 4)
+    double *conserved_rd, // :: $.shape == (ni + 4, nj, 4)
+    double *conserved_wr, // :: $.shape == (ni + 4, nj, 4)
+    double polar_extent,
+    double a0,
+    double adot,
+    double time,
+    double rk_param,
+    double dt,
+    double jet_mdot,
+    double jet_gamma_beta,
+    double jet_theta,
+    double jet_duration,
+    int num_first_order_zones)
+;
+
+/* Number of zones for which srhd_2d_conserved_to_primitive hit one of the reference's
+ * fatal conditions since the last call (device counter read back: synchronises).
+ * out[0] receives the count; n must be 1. */
+SFHIP_API int sfhip_srhd_2d_failures(
+    int n,
+    double *out) // :: $.numel() >= 1
+;
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,8 +33,11 @@ import sys
 REFERENCE = os.environ.get("SAILFISH_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
-SOLVERS = ("cbdiso_2d", "cbdgam_2d")
+SOLVERS = ("cbdiso_2d", "cbdgam_2d", "srhd_2d")
 FLAVOURS = {"cpu": ["-DEXEC_MODE=0"], "omp": ["-DEXEC_MODE=1", "-fopenmp"]}
+# srhd_2d takes PLM_THETA / MACH_CEILING as define_macros from its Solver (srhd_2d.py:225-233; defaults
+# srhd_2d.py:66-67).  Extra builds with other values pin the oracle's run-time settings.
+MACRO_VARIANTS = {"srhd_2d": {"": [], "_theta2": ["-DPLM_THETA=2.0", "-DMACH_CEILING=100.0"]}}
 
 
 def kernel_lib_header():
@@ -62,16 +65,19 @@ def build(verbose=True):
             # library.py:168 joins header and code with a single space
             code = f"{header} {f.read()}"
         for flavour, flags in FLAVOURS.items():
-            target = os.path.join(OUT, f"{solver}_{flavour}.so")
-            if os.path.exists(target) and os.path.getmtime(target) > max(
-                os.path.getmtime(src_path), os.path.getmtime(__file__)
-            ):
-                continue
-            cmd = ["gcc", "-std=c99", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
-                   *flags, "-x", "c", "-", "-o", target, "-lm"]
-            if verbose:
-                print("[build_ref]", " ".join(cmd), "<", src_path)
-            subprocess.run(cmd, input=code.encode(), check=True)
+            for suffix, macros in MACRO_VARIANTS.get(solver, {"": []}).items():
+                target = os.path.join(OUT, f"{solver}_{flavour}{suffix}.so")
+                if os.path.exists(target) and os.path.getmtime(target) > max(
+                    os.path.getmtime(src_path), os.path.getmtime(__file__)
+                ):
+                    continue
+                # -w: srhd_2d.c calls printf/exit without including their headers (the reference's own
+                # build only warns about it as well)
+                cmd = ["gcc", "-std=c99", "-O3", "-fPIC", "-shared", "-ffp-contract=off", "-w",
+                       *flags, *macros, "-x", "c", "-", "-o", target, "-lm"]
+                if verbose:
+                    print("[build_ref]", " ".join(cmd), "<", src_path)
+                subprocess.run(cmd, input=code.encode(), check=True)
     return True
 
 

@@ -140,3 +140,66 @@ def zone_relative_error(a, b, interior=True):
     num = np.abs(a - b).max(axis=-1)
     den = np.maximum(np.abs(b).max(axis=-1), 1e-300)
     return float((num / den).max())
+
+
+# ---------------------------------------------------------------------------
+# srhd_2d: log-spherical mesh, (ni + 4, nj, 4) arrays with guards in i only
+# ---------------------------------------------------------------------------
+def srhd_case(seed=0, ni=24, nj=20, i0=0, zones_per_decade=40, adot=0.0, time=1.0, rk_param=0.0, jet=False,
+              num_first_order_zones=0, polar_extent=np.pi, cold=False):
+    """
+    Seeded, physical srhd_2d state on rows [i0, i0 + ni) of a log mesh starting at r = 1:
+    rho in [0.1, 2], gamma-beta u_r in [-1, 3], u_q in [-1, 1], p in [0.01, 2] modulated by a smooth
+    profile (so the limiter sees both smooth and jagged data).  `cold` lowers the pressure by 1e-9
+    so that conserved_to_primitive's Mach-ceiling floor engages.
+    """
+    rng = np.random.default_rng(seed)
+    faces = np.array([10.0 ** (i / zones_per_decade) for i in range(i0, i0 + ni + 1)])
+    shape = (ni + 4, nj, 4)
+    ii = np.arange(ni + 4)[:, None] / (ni + 4)
+    jj = (np.arange(nj)[None, :] + 0.5) / nj
+    wave = 1.0 + 0.3 * np.sin(5.0 * ii) * np.cos(3.0 * jj)
+    prim = np.empty(shape)
+    prim[..., 0] = rng.uniform(0.1, 2.0, shape[:2]) * wave
+    prim[..., 1] = rng.uniform(-1.0, 3.0, shape[:2]) * wave
+    prim[..., 2] = rng.uniform(-1.0, 1.0, shape[:2])
+    prim[..., 3] = rng.uniform(0.01, 2.0, shape[:2]) * wave * (1e-9 if cold else 1.0)
+    a0 = 0.0 if adot else 1.0
+    return dict(
+        shape=(ni, nj), faces=faces, prim=prim, polar_extent=polar_extent, a0=a0, adot=adot, time=time,
+        scale_factor=a0 + adot * time, rk_param=rk_param, dt=1e-3 * (a0 + adot * time),
+        jet=(0.05, 8.0, 0.2, 5.0) if jet else (0.0, 0.0, 0.0, 0.0), nfo=num_first_order_zones,
+    )
+
+
+def srhd_conserved(lib, c, prim=None):
+    """(ni + 4, nj, 4) conserved array whose interior is p2c(prim interior) by `lib`; guards zero."""
+    prim = c["prim"] if prim is None else prim
+    ni, nj = c["shape"]
+    inner = np.ascontiguousarray(prim[2:-2])
+    out = np.zeros_like(inner)
+    lib.call("srhd_2d_primitive_to_conserved", c["shape"], c["faces"], inner, out, c["polar_extent"], c["scale_factor"])
+    cons = np.zeros_like(prim)
+    cons[2:-2] = out
+    return cons
+
+
+def srhd_advance_args(c, cons_rk, prim, cons_rd, cons_wr):
+    return (c["faces"], cons_rk, prim, cons_rd, cons_wr, c["polar_extent"], c["a0"], c["adot"], c["time"],
+            c["rk_param"], c["dt"], *c["jet"], c["nfo"])
+
+
+def srhd_branch_matrix():
+    return [
+        dict(),
+        dict(rk_param=0.5),
+        dict(adot=0.7, time=1.3),
+        dict(adot=0.7, time=1.3, rk_param=1.0 / 3.0, i0=7),
+        dict(jet=True, time=1.2),
+        dict(jet=True, time=9.0),                 # after the jet has switched off: innermost zones held
+        dict(jet=True, time=1.2, adot=0.4, num_first_order_zones=5),
+        dict(num_first_order_zones=100),          # first order everywhere
+        dict(ni=3, nj=2),
+        dict(ni=1, nj=1),
+        dict(polar_extent=0.5 * np.pi, nj=33, ni=9),
+    ]

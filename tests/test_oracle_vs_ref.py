@@ -70,3 +70,71 @@ def test_gam_wavespeed_p2c_rate_bitwise():
         ORC.call(name, c["shape"], *args_of(a))
         REF_GAM.call(name, c["shape"], *args_of(b))
         assert np.array_equal(a, b), name
+
+
+# ---------------------------------------------------------------------------
+# srhd_2d (oracle/sf_oracle_srhd.c); two compiled references: default macros, and
+# PLM_THETA=2.0 / MACH_CEILING=100 to pin the oracle's run-time settings
+# ---------------------------------------------------------------------------
+REF_SRHD = {(1.5, 1e6): oracle.ref("srhd_2d"), (2.0, 100.0): oracle.ref("srhd_2d", "cpu_theta2")}
+need_srhd = pytest.mark.skipif(REF_SRHD[(1.5, 1e6)] is None, reason="compiled reference (oracle/_ref) not available")
+SRHD_IDS = lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()) or "default"  # noqa: E731
+
+
+@need_srhd
+@pytest.mark.parametrize("macros", list(REF_SRHD))
+@pytest.mark.parametrize("kw", cases.srhd_branch_matrix(), ids=SRHD_IDS)
+def test_srhd_advance_bitwise(kw, macros):
+    ref = REF_SRHD[macros]
+    ORC.dll.sfo_srhd_2d_set_macros.argtypes = [oracle.ctypes.c_double] * 2
+    ORC.dll.sfo_srhd_2d_set_macros(*macros)
+    try:
+        c = cases.srhd_case(seed=13, **kw)
+        cons_rd = cases.srhd_conserved(ref, c)
+        cons_rk = cases.srhd_conserved(ref, c, prim=c["prim"] * 1.01)
+        out_o = np.full_like(c["prim"], -7.0)
+        out_r = np.full_like(c["prim"], -7.0)
+        ORC.call("srhd_2d_advance_rk", c["shape"], *cases.srhd_advance_args(c, cons_rk, c["prim"], cons_rd, out_o))
+        ref.call("srhd_2d_advance_rk", c["shape"], *cases.srhd_advance_args(c, cons_rk, c["prim"], cons_rd, out_r))
+        assert np.array_equal(out_o, out_r)
+        assert np.all(out_o[:2] == -7.0) and np.all(out_o[-2:] == -7.0)  # guards untouched
+        if c["jet"][0] > 0.0 and c["time"] > 6.0:
+            assert np.all(out_o[2] == -7.0)  # jet off: innermost row is not written at all
+    finally:
+        ORC.dll.sfo_srhd_2d_set_macros(1.5, 1e6)
+
+
+@need_srhd
+@pytest.mark.parametrize("macros", list(REF_SRHD))
+@pytest.mark.parametrize("cold", [False, True])
+@pytest.mark.parametrize("adot", [0.0, 0.15])
+def test_srhd_p2c_c2p_wavespeed_bitwise(macros, cold, adot):
+    ref = REF_SRHD[macros]
+    ORC.dll.sfo_srhd_2d_set_macros.argtypes = [oracle.ctypes.c_double] * 2
+    ORC.dll.sfo_srhd_2d_set_macros(*macros)
+    try:
+        c = cases.srhd_case(seed=21, ni=30, nj=17, adot=adot, time=1.4, cold=cold)
+        cons_o, cons_r = cases.srhd_conserved(ORC, c), cases.srhd_conserved(ref, c)
+        assert np.array_equal(cons_o, cons_r)
+        rng = np.random.default_rng(5)
+        guess = c["prim"].copy()
+        guess[..., 3] *= rng.uniform(0.7, 1.4, guess.shape[:2])
+        results = []
+        for lib in (ORC, ref):
+            p = guess.copy()
+            u2 = np.full_like(cons_r, -3.0)
+            lib.call("srhd_2d_conserved_to_primitive", c["shape"], c["faces"], cons_r, u2, p, c["polar_extent"],
+                     c["scale_factor"])
+            w = np.full(c["shape"], -1.0)
+            lib.call("srhd_2d_max_wavespeeds", c["shape"], c["faces"], p, w, c["adot"])
+            results.append((p, u2, w))
+        for a, b in zip(*results):
+            assert np.array_equal(a, b)
+        p, u2, w = results[0]
+        floored = np.any(u2[2:-2] != cons_r[2:-2], axis=-1)
+        assert floored.any() == (cold and macros[1] == 100.0)  # the Mach-ceiling floor engages only there
+        if not cold:
+            assert np.allclose(p[2:-2], c["prim"][2:-2], rtol=1e-9)
+        assert ORC.dll.sfo_srhd_2d_failures() == 0
+    finally:
+        ORC.dll.sfo_srhd_2d_set_macros(1.5, 1e6)
