@@ -17,6 +17,7 @@
 #include "sf_gam.hpp"
 #include "sf_iso.hpp"
 #include "sf_reduce.hpp"
+#include "sf_srhd.hpp"
 #include "sfhip.h"
 
 namespace {
@@ -645,6 +646,176 @@ int sfhip_cbdgam_2d_reductions(
         make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
         constant_softening, gamma_law_index, primitive, xcoord, ycoord, num_diagnostics, spec,
         workspace_len, workspace, sums);
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// srhd_2d -- reference-named entry points
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int SR_MAX_DEVICES = 64;
+thread_local double t_sr_theta = 1.5;         // srhd_2d.py:66 (Options.plm_theta)
+thread_local double t_sr_mach_ceiling = 1e6;  // srhd_2d.py:67
+
+// Per-device state of the srhd entry points, created on first use (the one place this library
+// allocates): the polar trigonometry table, filled on the host with libm so that zone volumes and
+// face areas carry exactly the reference's bits, and the conserved_to_primitive failure counter.
+struct SrhdDeviceState {
+    int nj = -1;
+    double polar_extent = 0.0;
+    double *trig = nullptr;        // sin(dq j), j = 0..nj, then cos(dq j), j = 0..nj
+    unsigned int *failures = nullptr;
+};
+SrhdDeviceState g_sr[SR_MAX_DEVICES];
+
+int srhd_state(int nj, double polar_extent, SrhdDeviceState **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    if (dev < 0 || dev >= SR_MAX_DEVICES) return fail(-1, "srhd_2d: device index out of range");
+    SrhdDeviceState &st = g_sr[dev];
+    if (!st.failures) {
+        e = hipMalloc((void **)&st.failures, sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(st.failures, 0, sizeof(unsigned int));
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    if (st.nj != nj || memcmp(&st.polar_extent, &polar_extent, sizeof(double)) != 0) {
+        if (st.trig) {
+            hipDeviceSynchronize(); // kernels of an earlier mesh may still be reading the old table
+            hipFree(st.trig);
+            st.trig = nullptr;
+            st.nj = -1;
+        }
+        const size_t n = (size_t)nj + 1;
+        double *host = (double *)malloc(2 * n * sizeof(double));
+        if (!host) return fail(-1, "srhd_2d: out of host memory");
+        const double dq = polar_extent / nj; // srhd_2d.c:524
+        for (size_t j = 0; j < n; ++j) {
+            const double q = dq * (double)j; // dq * (j + 0) and dq * (j + 1) of the reference
+            host[j] = sin(q);
+            host[n + j] = cos(q);
+        }
+        e = hipMalloc((void **)&st.trig, 2 * n * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(st.trig, host, 2 * n * sizeof(double), hipMemcpyHostToDevice);
+        free(host);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+        st.nj = nj;
+        st.polar_extent = polar_extent;
+    }
+    *out = &st;
+    return 0;
+}
+
+int srhd_fill(sf::SrhdParams &P, int ni, int nj, const double *faces, double polar_extent, SrhdDeviceState **st)
+{
+    if (ni < 1 || nj < 1 || !faces) return fail(-1, "srhd_2d: bad shape or null face_positions");
+    int rc = srhd_state(nj, polar_extent, st);
+    if (rc) return rc;
+    memset(&P, 0, sizeof(P));
+    P.ni = ni; P.nj = nj;
+    P.polar_extent = polar_extent;
+    P.dq = polar_extent / nj;
+    P.theta = t_sr_theta;
+    P.mach_ceiling2 = pow(t_sr_mach_ceiling, 2.0); // srhd_2d.c:156, host libm as in the reference
+    P.faces = faces;
+    P.sinq = (*st)->trig;
+    P.cosq = (*st)->trig + (nj + 1);
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int sfhip_srhd_2d_set_macros(int n, double plm_theta, double mach_ceiling)
+{
+    if (n != 1 || !(plm_theta >= 1.0 && plm_theta <= 2.0) || !(mach_ceiling > 0.0))
+        return fail(-1, "sfhip_srhd_2d_set_macros: need n == 1, 1 <= plm_theta <= 2, mach_ceiling > 0");
+    t_sr_theta = plm_theta;
+    t_sr_mach_ceiling = mach_ceiling;
+    return 0;
+}
+
+int srhd_2d_primitive_to_conserved(int ni, int nj, double *face_positions, double *primitive, double *conserved,
+                                   double polar_extent, double scale_factor)
+{
+    if (!primitive || !conserved) return fail(-1, "srhd_2d_primitive_to_conserved: null array");
+    sf::SrhdParams P;
+    SrhdDeviceState *st;
+    int rc = srhd_fill(P, ni, nj, face_positions, polar_extent, &st);
+    if (rc) return rc;
+    P.scale_factor = scale_factor;
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::srhd_p2c_kernel, grid, block, 0, t_stream, P, primitive, conserved);
+    return check_launch("srhd_2d_primitive_to_conserved");
+}
+
+int srhd_2d_conserved_to_primitive(int ni, int nj, double *face_positions, double *conserved1, double *conserved2,
+                                   double *primitive, double polar_extent, double scale_factor)
+{
+    if (!conserved1 || !conserved2 || !primitive) return fail(-1, "srhd_2d_conserved_to_primitive: null array");
+    sf::SrhdParams P;
+    SrhdDeviceState *st;
+    int rc = srhd_fill(P, ni, nj, face_positions, polar_extent, &st);
+    if (rc) return rc;
+    P.scale_factor = scale_factor;
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::srhd_c2p_kernel, grid, block, 0, t_stream, P, conserved1, conserved2, primitive, st->failures);
+    return check_launch("srhd_2d_conserved_to_primitive");
+}
+
+int srhd_2d_max_wavespeeds(int ni, int nj, double *face_positions, double *primitive, double *wavespeed, double adot)
+{
+    if (ni < 1 || nj < 1 || !face_positions || !primitive || !wavespeed) return fail(-1, "srhd_2d_max_wavespeeds: bad arguments");
+    sf::SrhdParams P;
+    memset(&P, 0, sizeof(P));
+    P.ni = ni; P.nj = nj; P.faces = face_positions; P.adot = adot;
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::srhd_wavespeed_kernel, grid, block, 0, t_stream, P, primitive, wavespeed);
+    return check_launch("srhd_2d_max_wavespeeds");
+}
+
+int srhd_2d_advance_rk(int ni, int nj, double *face_positions, double *conserved_rk, double *primitive_rd,
+                       double *conserved_rd, double *conserved_wr, double polar_extent, double a0, double adot,
+                       double time, double rk_param, double dt, double jet_mdot, double jet_gamma_beta,
+                       double jet_theta, double jet_duration, int num_first_order_zones)
+{
+    if (!conserved_rk || !primitive_rd || !conserved_rd || !conserved_wr) return fail(-1, "srhd_2d_advance_rk: null array");
+    if (conserved_wr == conserved_rd || conserved_wr == conserved_rk)
+        return fail(-1, "srhd_2d_advance_rk: conserved_wr must not alias an input");
+    sf::SrhdParams P;
+    SrhdDeviceState *st;
+    int rc = srhd_fill(P, ni, nj, face_positions, polar_extent, &st);
+    if (rc) return rc;
+    P.a0 = a0; P.adot = adot; P.time = time; P.rk_param = rk_param; P.dt = dt;
+    P.jet_mdot = jet_mdot; P.jet_gamma_beta = jet_gamma_beta; P.jet_theta = jet_theta; P.jet_duration = jet_duration;
+    P.num_first_order_zones = num_first_order_zones;
+    dim3 block(256), grid((nj + 255) / 256, ni);
+    hipLaunchKernelGGL(sf::srhd_advance_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
+                       conserved_wr);
+    return check_launch("srhd_2d_advance_rk");
+}
+
+int sfhip_srhd_2d_failures(int n, double *out)
+{
+    if (n != 1 || !out) return fail(-1, "sfhip_srhd_2d_failures: bad arguments");
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    unsigned int count = 0;
+    if (dev >= 0 && dev < SR_MAX_DEVICES && g_sr[dev].failures) {
+        e = hipStreamSynchronize(t_stream);
+        if (e == hipSuccess) e = hipMemcpy(&count, g_sr[dev].failures, sizeof(count), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(g_sr[dev].failures, 0, sizeof(count));
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    const double value = (double)count;
+    e = hipMemcpy(out, &value, sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
 }
 
 } // extern "C"
