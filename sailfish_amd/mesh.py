@@ -1,9 +1,15 @@
 """
-The one mesh the cbdiso_2d / cbdgam_2d solvers accept: a uniform 2-d Cartesian
-grid (reference: ``sailfish/mesh.py:175-261``).  Patch extents handed to the
-kernels come from ``vertex_coordinates`` and must be computed with exactly these
-expressions for multi-patch runs to reproduce the reference's coordinates.
+Meshes of the solvers built here.
+
+``PlanarCartesian2DMesh`` is the one mesh the cbdiso_2d / cbdgam_2d solvers accept: a
+uniform 2-d Cartesian grid (reference: ``sailfish/mesh.py:175-261``).  Patch extents
+handed to the kernels come from ``vertex_coordinates`` and must be computed with exactly
+these expressions for multi-patch runs to reproduce the reference's coordinates.
+
+``LogSphericalMesh`` (reference: ``sailfish/mesh.py:52-172``) is srhd_2d's mesh:
+logarithmic radial zones, uniform polar zones, optional homologous expansion.
 """
+from math import log, log10, pi
 from typing import NamedTuple
 
 
@@ -65,3 +71,85 @@ class PlanarCartesian2DMesh(NamedTuple):
         xa, ya = self.vertex_coordinates(di[0], dj[0])
         xb, yb = self.vertex_coordinates(di[1], dj[1])
         return PlanarCartesian2DMesh(xa, ya, xb, yb, di[1] - di[0], dj[1] - dj[0])
+
+
+class LogSphericalMesh(NamedTuple):
+    """
+    Logarithmically spaced radial zones (and, with ``polar_grid``, uniformly spaced polar
+    zones); comoving coordinates are fixed, proper distances scale with
+    ``scale_factor(time) = scale_factor_derivative * time`` when the mesh expands.
+    Face positions, zone counts and the polar spacing use the reference's expressions
+    (mesh.py:60-172) so that the kernels receive identical numbers.
+    """
+
+    r0: float = 1.0
+    r1: float = 10.0
+    num_zones_per_decade: int = 1000
+    scale_factor_derivative: float = None
+    polar_grid: bool = False
+    polar_extent: float = pi
+
+    def __str__(self):
+        if self.scale_factor_derivative is None:
+            motion = "no expansion"
+        else:
+            motion = f"homologous with a-dot = {self.scale_factor_derivative:0.2f}"
+        return (f"<log spherical: ({self.r0} -> {self.r1}), {motion}, "
+                f"{self.num_zones_per_decade} zones per decade, shape {self.shape}>")
+
+    def scale_factor(self, time):
+        return 1.0 if self.scale_factor_derivative is None else self.scale_factor_derivative * time
+
+    def min_spacing(self, time=None):
+        a, b = self.faces(0, 1)
+        return (b - a) * self.scale_factor(time)
+
+    @property
+    def num_radial_zones(self):
+        return int(log10(self.r1 / self.r0) * self.num_zones_per_decade)
+
+    @property
+    def num_polar_zones(self):
+        if not self.polar_grid:
+            raise ValueError("only defined for a 2D spherical polar mesh")
+        return int(self.num_zones_per_decade * self.polar_extent / log(10))
+
+    @property
+    def polar_spacing(self):
+        return self.polar_extent / self.num_polar_zones
+
+    @property
+    def shape(self):
+        return (self.num_radial_zones, self.num_polar_zones) if self.polar_grid else (self.num_radial_zones,)
+
+    @property
+    def num_total_zones(self):
+        total = 1
+        for n in self.shape:
+            total *= n
+        return total
+
+    def faces(self, i0=0, i1=None):
+        """Comoving radial face positions of zones [i0, i1): i1 - i0 + 1 values."""
+        if i1 is None:
+            i1 = self.shape[0]
+        k = 1.0 / self.num_zones_per_decade
+        return [self.r0 * 10 ** (i * k) for i in range(i0, i1 + 1)]
+
+    def zone_center(self, t, i):
+        k = 1.0 / self.num_zones_per_decade
+        return self.r0 * 10 ** ((i + 0.5) * k) * self.scale_factor(t)
+
+    def zone_centers(self, t, i0=0, i1=None):
+        return [self.zone_center(t, i) for i in range(i0, i1 or self.shape[0])]
+
+    def cell_coordinates(self, t, i, j):
+        return self.zone_center(t, i), (j + 0.5) * self.polar_spacing
+
+    def radial_vertices(self, time):
+        a = self.scale_factor(time)
+        return [r * a for r in self.faces()]
+
+    @property
+    def polar_vertices(self):
+        return [j * self.polar_spacing for j in range(self.num_polar_zones + 1)]

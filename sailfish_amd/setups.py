@@ -18,7 +18,7 @@ from math import exp, pi, sqrt
 
 import numpy as np
 
-from .mesh import PlanarCartesian2DMesh
+from .mesh import LogSphericalMesh, PlanarCartesian2DMesh
 from .physics.circumbinary import EquationOfState, PointMass, SinkModel, ViscosityModel
 from .physics.kepler import OrbitalElements
 
@@ -260,7 +260,202 @@ class CylindricalExplosion(Setup):
         return "cbdiso_2d" if self.is_isothermal else "cbdgam_2d"
 
 
-SETUPS = {"circumbinary-disk": CircumbinaryDisk, "cylindrical-explosion": CylindricalExplosion}
+class UniformPolar(Setup):
+    """Uniform gas at rest on a polar mesh: exercises srhd_2d's geometrical source terms (simple2d.py:13-37)."""
+
+    default_end_time = 1.0
+    default_resolution = 100
+
+    def primitive(self, t, coords, primitive):
+        primitive[0] = 1.0
+        primitive[1] = 0.0
+        primitive[2] = 0.0
+        primitive[3] = 1.0
+
+    def mesh(self, num_zones_per_decade):
+        return LogSphericalMesh(1.0, 50.0, num_zones_per_decade, polar_grid=True)
+
+    @property
+    def physics(self):
+        return dict()
+
+    @property
+    def solver(self):
+        return "srhd_2d"
+
+
+class _WindEnvelope:
+    """
+    The ballistic medium of the envelope-shock problem (envelope_shock.py:12-88): shells of mass
+    coordinate m leave the origin at time m / mdot_wind with gamma-beta u_wind + (m / m1)^-psi and
+    coast.  Expressions are kept operation for operation: the initial data must carry the
+    reference's bits.
+    """
+
+    t_delay = 1.0
+    m1 = 1.0
+    psi = 0.25
+    m_cloud = 1e5 * m1
+    u_wind = 0.1
+    mdot_wind = m_cloud / t_delay
+
+    @classmethod
+    def launch_time(cls, m):
+        return m / cls.mdot_wind
+
+    @classmethod
+    def gamma_beta(cls, m):
+        return cls.u_wind + (m / cls.m1) ** (-cls.psi)
+
+    @classmethod
+    def gamma_beta_prime(cls, m):
+        return -((m / cls.m1) ** (-cls.psi)) * cls.psi / m
+
+    @classmethod
+    def speed(cls, m):
+        u = cls.gamma_beta(m)
+        return u / (1 + u**2) ** 0.5
+
+    @classmethod
+    def speed_prime(cls, m):
+        u = cls.gamma_beta(m)
+        du_dm = cls.gamma_beta_prime(m)
+        dv_du = (1 + u**2) ** (-3 / 2)
+        return dv_du * du_dm
+
+    @classmethod
+    def radius(cls, m, t):
+        return cls.speed(m) * (t - cls.launch_time(m))
+
+    @classmethod
+    def density(cls, m, t):
+        t0 = cls.launch_time(m)
+        t0_prime = 1.0 / cls.mdot_wind
+        u = cls.gamma_beta(m)
+        u_prime = cls.gamma_beta_prime(m)
+        mdot_inverse = t0_prime - u_prime / u * (t - t0) / (1 + u**2)
+        r = cls.radius(m, t)
+        return 1.0 / (4 * pi * r**2 * u * mdot_inverse)
+
+    @classmethod
+    def mass_at(cls, r, t):
+        """Newton iteration for the shell at radius r (envelope_shock.py:64-88)."""
+        m = 1e-12
+        n = 0
+        while True:
+            fm = r - cls.radius(m, t)
+            v = cls.speed(m)
+            t0 = cls.launch_time(m)
+            dv = cls.speed_prime(m)
+            dt0 = 1.0 / cls.mdot_wind
+            gm = -(dv * (t - t0) - v * dt0)
+            m -= fm / gm
+            if abs(fm) < 1e-10:
+                return m
+            if n > 200:
+                raise ValueError("too many iterations")
+            n += 1
+
+
+class EnvelopeShock(Setup):
+    """
+    A relativistic shell or jet launched into a homologous relativistic envelope
+    (envelope_shock.py:91-264); with ``polar_extent > 0`` it is the srhd_2d workload of
+    BASELINE.json configs[4].  The 1-d variant (srhd_1d) is not built here.
+    """
+
+    u_shell = 30.0
+    m_shell = 1.0
+    w_shell = 1.0
+    q_shell = 0.1
+    t_start = 1.0
+    r_inner = 0.1
+    r_outer = 1.0
+    expand = True
+    jet_energy = 0.0
+    jet_gamma_beta = 10.0
+    jet_theta = 0.1
+    jet_duration = 1.0
+    polar_extent = 0.5
+
+    default_end_time = 1.0
+    default_resolution = 800
+
+    def validate(self):
+        if self.polar_extent <= 0.0:
+            raise SetupError("this package builds the 2d (srhd_2d) variant only: polar_extent must be > 0")
+        if self.jet_energy > 0.0 and self.u_shell > 0.0:
+            raise SetupError("we don't simulate a jet and a shell at the same time")
+
+    @property
+    def start_time(self):
+        return self.t_start
+
+    def envelope_state(self, r, t):
+        m = _WindEnvelope.mass_at(r, t)
+        d = _WindEnvelope.density(m, t)
+        u = _WindEnvelope.gamma_beta(m)
+        return m, d, u, 1e-6 * d
+
+    def shell_u_profile_mass(self, m):
+        if m < self.m_shell:
+            return 0.0
+        return self.u_shell * exp(-(m / self.m_shell - 1.0) / self.w_shell)
+
+    def shell_u_profile_polar(self, q):
+        return exp(-((q / self.q_shell) ** 2))
+
+    def primitive(self, t, coord, primitive):
+        r, q = coord
+        m, d, u, p = self.envelope_state(r, t)
+        primitive[0] = d
+        primitive[1] = u + self.shell_u_profile_mass(m) * self.shell_u_profile_polar(q)
+        primitive[2] = 0.0
+        primitive[3] = p
+
+    def primitive_rows(self, t, mesh, i0, i1):
+        """Rows [i0, i1) at once: the radial profile is evaluated once per row (the reference caches it per
+        (r, t), envelope_shock.py:243), the polar profile once per column; same scalar calls, same bits."""
+        nj = mesh.shape[1]
+        out = np.zeros([i1 - i0, nj, 4])
+        polar = [self.shell_u_profile_polar(mesh.cell_coordinates(t, 0, j)[1]) for j in range(nj)]
+        for i in range(i0, i1):
+            m, d, u, p = self.envelope_state(mesh.cell_coordinates(t, i, 0)[0], t)
+            du = self.shell_u_profile_mass(m)
+            out[i - i0, :, 0] = d
+            out[i - i0, :, 1] = [u + du * f for f in polar]
+            out[i - i0, :, 3] = p
+        return out
+
+    @property
+    def physics(self):
+        if self.jet_energy == 0.0:
+            return dict()
+        jet_gamma = (self.jet_gamma_beta * self.jet_gamma_beta + 1.0) ** 0.5
+        jet_mdot = self.jet_energy / ((jet_gamma - 1.0) * self.jet_duration / _WindEnvelope.m_cloud)
+        return dict(jet_mdot=jet_mdot, jet_gamma_beta=self.jet_gamma_beta, jet_theta=self.jet_theta,
+                    jet_duration=self.jet_duration)
+
+    def mesh(self, num_zones_per_decade):
+        return LogSphericalMesh(
+            r0=self.r_inner, r1=self.r_outer, num_zones_per_decade=num_zones_per_decade,
+            scale_factor_derivative=(1.0 / self.t_start) if self.expand else None,
+            polar_grid=True, polar_extent=self.polar_extent * pi,
+        )
+
+    @property
+    def solver(self):
+        return "srhd_2d"
+
+    @property
+    def boundary_condition(self):
+        return ("jet", "outflow") if self.jet_energy > 0.0 else "outflow"
+
+
+SETUPS = {
+    "circumbinary-disk": CircumbinaryDisk, "cylindrical-explosion": CylindricalExplosion,
+    "uniform-polar": UniformPolar, "envelope-shock": EnvelopeShock,
+}
 
 
 def make_setup(name, **model_parameters):

@@ -20,12 +20,12 @@ def register_solver_extension(solver_name, solver_module):
 
 
 def make_solver(name, physics, options, **kwargs):
-    from . import cbdgam_2d, cbdiso_2d
+    from . import cbdgam_2d, cbdiso_2d, srhd_2d
 
-    solvers = dict(cbdiso_2d=cbdiso_2d, cbdgam_2d=cbdgam_2d, **extension_solvers)
+    solvers = dict(cbdiso_2d=cbdiso_2d, cbdgam_2d=cbdgam_2d, srhd_2d=srhd_2d, **extension_solvers)
     if name not in solvers:
         raise SolverInitializationError(f"no solver named {name}; this package builds {sorted(solvers)}")
     try:
-        return solvers[name].Solver(physics=dict(physics), options=dict(options or {}), **kwargs)
-    except ValueError as e:
+        return solvers[name].Solver(physics=dict(physics or {}), options=dict(options or {}), **kwargs)
+    except (TypeError, ValueError) as e:
         raise SolverInitializationError(e)

@@ -620,20 +620,24 @@ class SolverBase:
         for k, p in local.items():
             lower, upper = self._neighbors(k)
             pc = getattr(p, array)
-            if lower is not None:
-                if lower in local:
-                    with p.execution_context:
-                        pc[:NG].copy_(getattr(local[lower], array)[-2 * NG:-NG], non_blocking=True)
-                else:
-                    ops.append(("send", pc[NG:2 * NG], self.owner(lower)))
-                    ops.append(("recv", pc[:NG], self.owner(lower)))
-            if upper is not None:
-                if upper in local:
-                    with p.execution_context:
-                        pc[-NG:].copy_(getattr(local[upper], array)[NG:2 * NG], non_blocking=True)
-                else:
-                    ops.append(("send", pc[-2 * NG:-NG], self.owner(upper)))
-                    ops.append(("recv", pc[-NG:], self.owner(upper)))
+            if lower is not None and lower in local:
+                with p.execution_context:
+                    pc[:NG].copy_(getattr(local[lower], array)[-2 * NG:-NG], non_blocking=True)
+            if upper is not None and upper in local:
+                with p.execution_context:
+                    pc[-NG:].copy_(getattr(local[upper], array)[NG:2 * NG], non_blocking=True)
+            # A message is named by the guard slab it fills: (destination patch, 0 lower | 1 upper).
+            if upper is not None and upper not in local:
+                ops.append(((upper, 0), "send", pc[-2 * NG:-NG], self.owner(upper)))
+                ops.append(((k, 1), "recv", pc[-NG:], self.owner(upper)))
+            if lower is not None and lower not in local:
+                ops.append(((lower, 1), "send", pc[NG:2 * NG], self.owner(lower)))
+                ops.append(((k, 0), "recv", pc[:NG], self.owner(lower)))
+        # Between two ranks, messages are matched in posting order (RCCL has no tags).  Posting in
+        # the order of the message names on both sides keeps the pairs aligned also when a rank
+        # exchanges several slabs with the same peer (two ranks, several patches, wrap-around halos).
+        ops.sort(key=lambda op: op[0])
+        ops = [op[1:] for op in ops]
         if not ops:
             return None
         dist = self.comm.dist

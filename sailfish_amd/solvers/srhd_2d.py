@@ -1,0 +1,352 @@
+"""
+2-D special-relativistic hydrodynamics on a log-spherical mesh, ``hip`` execution mode.
+
+Public surface follows the reference's ``sailfish/solvers/srhd_2d.py``: ``Options``
+(:64-68), ``Physics`` (:71-75), ``initial_condition`` (:49-61), ``Patch`` (:78-205) and
+``Solver`` (:208-407).  The arithmetic is in libsfhip.so (``csrc/sf_srhd.hpp``).
+
+First cut of this solver on the device: the data flow is the
+reference's own -- per RK stage ``conserved_to_primitive`` on every patch, ``set_bc`` on
+the primitive array, ``advance_rk`` -- with device-resident arrays.  What differs:
+
+* halos between patches are one contiguous slab copy (or an ``isend``/``irecv`` pair
+  between ranks) instead of a cupy slice assignment across devices;
+* PLM_THETA / MACH_CEILING, compile-time macros in the reference (:225-233), are library
+  settings re-asserted before every launch;
+* where the reference's C path prints and ``exit(1)``s on a failed primitive recovery,
+  ``Solver.check_failures()`` raises ``SolverError``.
+"""
+from logging import getLogger
+from typing import NamedTuple
+
+import numpy as np
+
+from ..kernel.system import to_host
+from ..mesh import LogSphericalMesh
+from ..subdivide import concat_on_host, lazy_reduce, subdivide
+from .cbd_common import Comm, HipBackend, SolverBase
+
+logger = getLogger(__name__)
+
+NUM_GUARD = 2
+NUM_CONS = 4
+
+BC_PERIODIC, BC_OUTFLOW, BC_INFLOW, BC_REFLECT, BC_FIXED, BC_JET = 1, 2, 3, 4, 5, 6
+BC_DICT = {"periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "inflow": BC_INFLOW, "reflect": BC_REFLECT,
+           "fixed": BC_FIXED, "jet": BC_JET}
+FILLED_BY_SET_BC = (BC_OUTFLOW, BC_INFLOW, BC_REFLECT)  # every other mode leaves the wrap-around halo in place
+
+
+class SolverError(Exception):
+    pass
+
+
+class Options(NamedTuple):
+    compute_wavespeed: bool = False
+    rk_order: int = 2
+    plm_theta: float = 1.5
+    mach_ceiling: float = 1e6
+
+
+class Physics(NamedTuple):
+    jet_mdot: float = 0.0
+    jet_gamma_beta: float = 0.0
+    jet_theta: float = 0.0
+    jet_duration: float = 0.0
+
+
+def initial_condition(setup, mesh, i0, i1, time):
+    """Primitive initial data of rows [i0, i1), shape (i1 - i0, nj, 4) (reference: srhd_2d.py:49-61)."""
+    if hasattr(setup, "primitive_rows"):
+        return setup.primitive_rows(time, mesh, i0, i1)
+    nj = mesh.shape[1]
+    primitive = np.zeros([i1 - i0, nj, NUM_CONS])
+    radii = [mesh.cell_coordinates(time, i, 0)[0] for i in range(i0, i1)]
+    angles = [mesh.cell_coordinates(time, 0, j)[1] for j in range(nj)]
+    for i, r in enumerate(radii):
+        for j, q in enumerate(angles):
+            setup.primitive(time, (r, q), primitive[i, j])
+    return primitive
+
+
+class Patch:
+    """Device buffers of one radial slab and the launches on them (reference: srhd_2d.py:78-205)."""
+
+    def __init__(self, setup, physics, options, time, conserved, mesh, index_range, num_first_order_zones,
+                 backend, context):
+        ng, nq = NUM_GUARD, NUM_CONS
+        i0, i1 = index_range
+        nj = mesh.shape[1]
+        self.lib = backend.lib
+        self.xp = xp = backend.xp
+        self.physics = physics
+        self.options = options
+        self.index_range = index_range
+        self.num_first_order_zones = num_first_order_zones
+        self.shape = shape = (i1 - i0, nj)
+        self.polar_extent = mesh.polar_extent
+        self.time = self.time0 = time
+        self.execution_context = context
+        try:  # srhd_2d.py:111-117
+            self.scale_factor_derivative = float(mesh.scale_factor_derivative)
+            self.scale_factor_initial = 0.0
+        except (TypeError, AttributeError):
+            self.scale_factor_initial = 1.0
+            self.scale_factor_derivative = 0.0
+
+        with self.execution_context:
+            self.faces = xp.array(mesh.faces(*index_range))
+            with_guard = xp.zeros([shape[0] + 2 * ng, nj, nq])
+            if conserved is None:
+                primitive = xp.array(initial_condition(setup, mesh, i0, i1, time))
+                interior = xp.zeros([shape[0], nj, nq])
+                self.assert_macros()
+                self.lib.srhd_2d_primitive_to_conserved[shape](
+                    self.faces, primitive, interior, mesh.polar_extent, mesh.scale_factor(time))
+                with_guard[ng:-ng] = interior
+            else:
+                with_guard[ng:-ng] = xp.array(conserved)
+            self.wavespeeds = xp.zeros(shape)
+            self.primitive1 = xp.zeros([shape[0] + 2 * ng, nj, nq])
+            self.conserved0 = with_guard.clone()
+            self.conserved1 = with_guard.clone()
+            self.conserved2 = with_guard
+
+    def assert_macros(self):
+        self.lib.sfhip_srhd_2d_set_macros[1](self.options.plm_theta, self.options.mach_ceiling)
+
+    @property
+    def scale_factor(self):
+        return self.scale_factor_initial + self.scale_factor_derivative * self.time
+
+    def recompute_primitive(self):
+        with self.execution_context:
+            self.assert_macros()
+            self.lib.srhd_2d_conserved_to_primitive[self.shape](
+                self.faces, self.conserved1, self.conserved2, self.primitive1, self.polar_extent, self.scale_factor)
+            self.conserved1, self.conserved2 = self.conserved2, self.conserved1
+
+    def advance_rk(self, rk_param, dt):
+        with self.execution_context:
+            self.assert_macros()
+            self.lib.srhd_2d_advance_rk[self.shape](
+                self.faces, self.conserved0, self.primitive1, self.conserved1, self.conserved2,
+                self.polar_extent, self.scale_factor_initial, self.scale_factor_derivative, self.time,
+                rk_param, dt,
+                self.physics.jet_mdot if self.index_range[0] == 0 else 0.0,
+                self.physics.jet_gamma_beta, self.physics.jet_theta, self.physics.jet_duration,
+                self.num_first_order_zones,
+            )
+        self.time = self.time0 * rk_param + (self.time + dt) * (1.0 - rk_param)  # srhd_2d.py:176
+        self.conserved1, self.conserved2 = self.conserved2, self.conserved1
+
+    def maximum_wavespeed(self):
+        """srhd_2d.py:179-188; returns a device scalar (the caller converts: lazy_reduce)."""
+        self.recompute_primitive()
+        with self.execution_context:
+            self.lib.srhd_2d_max_wavespeeds[self.shape](
+                self.faces, self.primitive1, self.wavespeeds, self.scale_factor_derivative)
+            return self.wavespeeds.max()
+
+    def new_iteration(self):
+        self.time0 = self.time
+        with self.execution_context:
+            self.conserved0.copy_(self.conserved1)
+
+    @property
+    def conserved(self):
+        return self.conserved1
+
+    @property
+    def primitive(self):
+        self.recompute_primitive()
+        return self.primitive1
+
+
+class Solver(SolverBase):
+    """Drives the srhd_2d kernels of libsfhip.so (reference: srhd_2d.py:208-407)."""
+
+    num_cons = NUM_CONS
+
+    def __init__(self, setup=None, mesh=None, time=0.0, solution=None, num_patches=None, mode="hip",
+                 physics=dict(), options=dict(), backend=None, distributed=None):
+        self._physics = physics = Physics(**(physics or {}))
+        self._options = options = Options(**options)
+        if type(mesh) is not LogSphericalMesh or not mesh.polar_grid:
+            raise ValueError("solver only supports a 2D log-spherical mesh")
+        if options.rk_order not in (1, 2, 3):
+            raise ValueError("solver only supports rk_order in 1, 2, 3")
+        try:
+            bcl, bcr = setup.boundary_condition
+        except ValueError:
+            bcl = bcr = setup.boundary_condition
+        try:
+            self.boundary_condition = BC_DICT[bcl], BC_DICT[bcr]
+        except KeyError:
+            raise ValueError(f"bad boundary condition {bcl}/{bcr}")
+        if backend is None:
+            if mode != "hip":
+                raise ValueError(f"sailfish_amd solvers implement execution mode 'hip' only (got {mode!r})")
+            backend = HipBackend()
+        self.backend = backend
+        self.mode = backend.mode
+        self.xp = backend.xp
+        self.mesh = mesh
+        self.setup = setup
+        self.num_guard = NUM_GUARD
+        self.fused = False
+        self.comm = Comm.auto(distributed)
+
+        world = self.comm.size
+        if num_patches is None or num_patches < world:
+            num_patches = world
+        if num_patches % world:
+            raise ValueError(f"num_patches ({num_patches}) must be a multiple of the number of ranks ({world})")
+        per_rank = num_patches // world
+        ranges = subdivide(mesh.shape[0], num_patches)
+        self.num_patches = num_patches
+        self.patch_ranges = ranges
+        self.local_ids = list(range(self.comm.rank * per_rank, (self.comm.rank + 1) * per_rank))
+        self.owner = lambda k: k // per_rank
+        logger.info(f"initiate with time={time:0.4f}")
+        logger.info(f"subdivide grid over {num_patches} patches on {world} rank(s)")
+        logger.info(f"mesh is {mesh}")
+
+        ndev = backend.num_devices()
+        if self.comm.enabled and backend.mode == "hip":
+            import os
+
+            base_device = int(os.environ.get("LOCAL_RANK", self.comm.rank % max(ndev, 1)))
+        else:
+            base_device = None
+        self.patches = []
+        for n, k in enumerate(self.local_ids):
+            a, b = ranges[k]
+            # extra diffusion near the jet inlet prevents crashes (srhd_2d.py:257-262)
+            num_first_order_zones = 512 if (k == 0 and bcl == "jet") else 0
+            device = base_device if base_device is not None else (n % max(ndev, 1))
+            self.patches.append(Patch(
+                setup, physics, options, time, solution[a:b] if solution is not None else None, mesh, (a, b),
+                num_first_order_zones, backend, backend.context(device)))
+        self._comm_stream = None
+        self._mass_cache = (None, None)
+        self.event_log = None
+
+    # ------------------------------------------------------------------ state
+    @property
+    def solution(self):
+        """Conserved variables, (ni, nj, 4) host array without guards (srhd_2d.py:291-293)."""
+        local = concat_on_host([p.conserved for p in self.patches], (NUM_GUARD, 0))
+        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+
+    @property
+    def primitive(self):
+        local = concat_on_host([p.primitive for p in self.patches], (NUM_GUARD, 0))
+        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+
+    @property
+    def recommended_cfl(self):
+        return 0.4
+
+    @property
+    def maximum_cfl(self):
+        return 16.0  # srhd_2d.py:315-322
+
+    def reductions(self):
+        return []
+
+    def maximum_wavespeed(self):
+        if not self._options.compute_wavespeed:
+            return 1.0
+        local = lazy_reduce(max, float, (p.maximum_wavespeed for p in self.patches),
+                            (p.execution_context for p in self.patches))
+        if self.comm.enabled:
+            t = self.patches[0].xp.array([local])
+            self.comm.max_scalar(t)
+            local = float(to_host(t)[0])
+        return local
+
+    def step(self, cfl_number, dx=None):
+        dx = self.mesh.min_spacing(self.time) if dx is None else dx
+        dt = dx / self.maximum_wavespeed() * cfl_number
+        self.advance(dt)
+        return dt
+
+    # --------------------------------------------------------------- advance
+    def advance(self, dt):
+        self.new_iteration()
+        for b in self.rk_parameters():
+            self.advance_rk(b, dt)
+
+    def new_iteration(self):
+        for p in self.patches:
+            p.new_iteration()
+
+    def advance_rk(self, rk_param, dt, *unused):
+        for p in self.patches:
+            p.recompute_primitive()
+        self.set_bc("primitive1")
+        for p in self.patches:
+            p.advance_rk(rk_param, dt)
+
+    def check_failures(self):
+        """Raises where the reference's C path would have printed [FATAL] and exited (srhd_2d.c:164-184)."""
+        total = 0
+        for p in self.patches:
+            with p.execution_context:
+                out = p.xp.zeros(1)
+                p.lib.sfhip_srhd_2d_failures[1](out)
+                total += int(to_host(out)[0])
+        if total:
+            raise SolverError(f"srhd_2d_conserved_to_primitive failed in {total} zone(s) "
+                              "(Newton iteration limit, non-positive energy or pressure)")
+
+    # ----------------------------------------------------------- boundaries
+    def _neighbors(self, k):
+        """
+        The reference copies halos with periodic wrap-around (srhd_2d.py:349-357) and then overwrites
+        the domain ends for outflow / inflow / reflect; the other modes (jet, fixed, periodic) keep the
+        wrapped rows, so the wrap is only skipped where it would be overwritten anyway.
+        """
+        n = self.num_patches
+        bcl, bcr = self.boundary_condition
+        lower = k - 1 if k > 0 else (None if bcl in FILLED_BY_SET_BC else n - 1)
+        upper = k + 1 if k < n - 1 else (None if bcr in FILLED_BY_SET_BC else 0)
+        return lower, upper
+
+    def set_bc(self, array):
+        ng = NUM_GUARD
+        self.finish_halo_exchange(self.start_halo_exchange(array))
+        bcl, bcr = self.boundary_condition
+        t = self.time
+        ni, nj = self.mesh.shape
+        flip = None
+        for k, p in zip(self.local_ids, self.patches):
+            pc = getattr(p, array)
+            with p.execution_context:
+                if k == 0:
+                    if bcl == BC_OUTFLOW:
+                        pc[:ng] = pc[ng:2 * ng]
+                    elif bcl == BC_INFLOW:
+                        rows = np.zeros([ng, nj, NUM_CONS])
+                        for i in range(-ng, 0):
+                            for j in range(nj):
+                                self.setup.primitive(t, self.mesh.cell_coordinates(t, i, j), rows[i + ng, j])
+                        pc[:ng] = p.xp.array(rows)
+                    elif bcl == BC_REFLECT:
+                        flip = p.xp.array([1.0, -1.0, 1.0, 1.0]) if flip is None else flip
+                        pc[0] = pc[3] * flip
+                        pc[1] = pc[2] * flip
+                if k == self.num_patches - 1:
+                    if bcr == BC_OUTFLOW:
+                        pc[-ng:] = pc[-2 * ng:-ng]
+                    elif bcr == BC_INFLOW:
+                        rows = np.zeros([ng, nj, NUM_CONS])
+                        for i in range(ni, ni + ng):
+                            for j in range(nj):
+                                self.setup.primitive(t, self.mesh.cell_coordinates(t, i, j), rows[i - ni, j])
+                        pc[-ng:] = p.xp.array(rows)
+                    elif bcr == BC_REFLECT:
+                        flip = p.xp.array([1.0, -1.0, 1.0, 1.0]) if flip is None else flip
+                        pc[-2] = pc[-3] * flip
+                        pc[-1] = pc[-4] * flip

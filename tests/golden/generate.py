@@ -27,7 +27,13 @@ Fixtures:
   gam_disk_64.npz       gamma-law disk 64^2, 20 steps (alpha viscosity, buffer)
   gam_cooling_48.npz    gamma-law with cooling 1e-2, 48^2, 10 steps
   gam_explosion_64.npz  gamma-law explosion 64^2, 20 steps
-Each solver fixture stores: initial primitive, final primitive, dt[], time[].
+  srhd_uniform_polar.npz        uniform-polar, 20 zones per decade, 10 RK2 steps (geometrical source terms)
+  srhd_envelope_shock_p3.npz    envelope-shock (u_shell 30), expanding polar mesh, 3 patches, wavespeed-based dt
+  srhd_envelope_jet_p2.npz      envelope-shock with the jet inflow boundary, 2 patches (first-order zones)
+  srhd_envelope_rk3_theta2.npz  rk_order 3, plm_theta 2.0, mach_ceiling 100 (the macro-configured build)
+                        srhd fixtures store the conserved solution (initial, final), the final primitive,
+                        dt[], time[].
+Each cbd solver fixture stores: initial primitive, final primitive, dt[], time[].
   iso_reductions_64_p2.npz, gam_reductions_48.npz
                         Solver.reductions() of the reference after 12 steps, for a list of
                         diagnostics covering every quantity / mass / term / radial-cut branch:
@@ -55,6 +61,7 @@ def reference_modules():
     import sailfish.setups  # noqa: F401  (registers setup classes)
     import sailfish.solvers.cbdgam_2d as ref_gam
     import sailfish.solvers.cbdiso_2d as ref_iso
+    import sailfish.solvers.srhd_2d as ref_srhd
     from sailfish.setup_base import SetupBase
     from sailfish.solvers import make_solver
 
@@ -62,12 +69,18 @@ def reference_modules():
         def load_cpu_module(self, code, name, mode="cpu", define_macros=dict()):
             import numpy
 
-            solver = "cbdiso_2d" if "MODULE: cbdiso_2d" in code else "cbdgam_2d"
-            self.module = CDLL(os.path.join(ROOT, "oracle", "_ref", f"{solver}_{mode}.so"))
+            solver = [n for n in ("cbdiso_2d", "cbdgam_2d", "srhd_2d") if f"MODULE: {n}" in code][0]
+            suffix = ""
+            if solver == "srhd_2d":
+                # the macro configurations oracle/build_ref.py compiles (define_macros, srhd_2d.py:225-233)
+                macros = (float(define_macros["PLM_THETA"]), float(define_macros["MACH_CEILING"]))
+                suffix = {(1.5, 1e6): "", (2.0, 100.0): "_theta2"}[macros]
+            self.module = CDLL(os.path.join(ROOT, "oracle", "_ref", f"{solver}_{mode}{suffix}.so"))
             self.xp = numpy
 
     ref_iso.Library = RefLibrary
     ref_gam.Library = RefLibrary
+    ref_srhd.Library = RefLibrary
     return SetupBase, make_solver
 
 
@@ -141,6 +154,27 @@ def run_reductions(SetupBase, make_solver, resolution, steps, diagnostics, model
                 num_patches=np.array(num_patches), model=np.array(json.dumps(model or {})))
 
 
+def run_srhd(SetupBase, make_solver, setup_name, resolution, steps, model=None, options=None, num_patches=1):
+    import json
+
+    setup = SetupBase.find_setup_class(setup_name)(**(model or {}))
+    mesh = setup.mesh(resolution)
+    solver = make_solver(setup.solver, setup.physics, options or {}, setup=setup, mesh=mesh,
+                         time=setup.start_time, solution=None, num_patches=num_patches, mode="cpu")
+    initial = solver.solution.copy()
+    cfl = solver.recommended_cfl
+    dts, times = [], []
+    for _ in range(steps):
+        dt = mesh.min_spacing(solver.time) / solver.maximum_wavespeed() * cfl  # driver.py:508-510
+        solver.advance(dt)
+        dts.append(dt)
+        times.append(solver.time)
+    return dict(initial=initial, final=solver.solution.copy(), final_primitive=solver.primitive.copy(),
+                dt=np.array(dts), time=np.array(times), cfl=np.array(cfl), resolution=np.array(resolution),
+                num_patches=np.array(num_patches), start_time=np.array(setup.start_time),
+                model=np.array(json.dumps(model or {})), options=np.array(json.dumps(options or {})))
+
+
 def kepler_fixture(SetupBase):
     rows = []
     times = np.concatenate([np.linspace(0.0, 13.0, 40), [0.1, 1e-3, 100.7, 6.283185307179586, 31.4, 1e3, 2.5, 7.7, 19.9, 50.0]])
@@ -173,10 +207,18 @@ def main():
     out["gam_reductions_48"] = run_reductions(SetupBase, make_solver, 48, 12, GAM_DIAGNOSTICS,
                                               model=dict(eos="gamma-law", constant_softening=False, domain_radius=3.0, mass_ratio=0.4, eccentricity=0.1,
                                                          sink_radius=0.1))
+    srhd = lambda *a, **k: run_srhd(SetupBase, make_solver, *a, **k)
+    out["srhd_uniform_polar"] = srhd("uniform-polar", 20, 10)
+    out["srhd_envelope_shock_p3"] = srhd("envelope-shock", 40, 8, model=dict(polar_extent=0.5), num_patches=3,
+                                         options=dict(compute_wavespeed=True))
+    out["srhd_envelope_jet_p2"] = srhd("envelope-shock", 40, 8, num_patches=2,
+                                       model=dict(polar_extent=0.5, u_shell=0.0, jet_energy=1e-3, jet_theta=0.3))
+    out["srhd_envelope_rk3_theta2"] = srhd("envelope-shock", 32, 6, model=dict(polar_extent=0.25, expand=False),
+                                           options=dict(rk_order=3, plm_theta=2.0, mach_ceiling=100.0))
     for name, data in out.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
         print(name, data["final"].shape if "final" in data else data["values"][:3],
-              "t_end", data["time"][-1] if data["time"].ndim else float(data["time"]))
+              "t_end", data["time"][-1] if data["time"].ndim else float(data["time"]), flush=True)
     np.savez_compressed(os.path.join(HERE, "kepler.npz"), rows=kepler_fixture(SetupBase))
     # one-patch == four-patch bitwise for the power-of-two mesh (recorded, then relied upon by tests)
     one = run("circumbinary-disk", 128, 20, num_patches=1)

@@ -32,7 +32,12 @@ class _Invocation:
         names = [a.name for a in sym.args][len(self.shape):]
         assert len(names) == len(args), (self.name, len(names), len(args))
         kw = dict(zip(names, args))
-        getattr(self.lib, "_" + self.name)(self.shape, kw, list(args))
+        handler = getattr(self.lib, "_" + self.name, None)
+        if handler is not None:
+            handler(self.shape, kw, list(args))
+        else:
+            # a reference-named kernel: the oracle has it under the same argument list
+            self.lib.orc.call(self.name, self.shape, *[_np(a) if hasattr(a, "numpy") else a for a in args])
 
 
 class _Kernel:
@@ -119,6 +124,15 @@ class OracleLibrary:
 
     def _sfhip_cbdgam_2d_reductions(self, shape, kw, args):
         self._reductions("cbdgam_2d", shape, kw)
+
+    def _sfhip_srhd_2d_set_macros(self, shape, kw, args):
+        import ctypes
+
+        self.orc.dll.sfo_srhd_2d_set_macros.argtypes = [ctypes.c_double] * 2
+        self.orc.dll.sfo_srhd_2d_set_macros(kw["plm_theta"], kw["mach_ceiling"])
+
+    def _sfhip_srhd_2d_failures(self, shape, kw, args):
+        kw["out"][0] = float(self.orc.dll.sfo_srhd_2d_failures())
 
     def _sfhip_timestep(self, shape, kw, args):
         with np.errstate(divide="ignore"):  # amax == 0 gives inf on the device too
