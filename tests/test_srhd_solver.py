@@ -109,10 +109,12 @@ def test_hip_solver_restart_and_failure_report():
     b = make_solver(setup.solver, setup.physics, {}, time=a.time, solution=a.solution, **kw)
     for s in (a, b):
         s.step(0.4)
-    # conserved_to_primitive starts its Newton iteration from the previous pressure, which a restart
-    # does not carry (the reference's checkpoint holds it, ours starts from zero like solution= does)
+    # conserved_to_primitive starts its Newton iteration from the previous pressure, which a restart from
+    # `solution=` does not carry (in the reference neither: srhd_2d.py:138-140 starts primitive1 at zero).
+    # The iteration stops at |f| < 1e-12 (D + tau) (srhd_2d.c:112), which for this cold gas (p = 1e-6 rho)
+    # is a 1e-6 relative pressure error: a restart is therefore only this close, by construction.
     scale = np.abs(a.solution).max(axis=-1, keepdims=True)
-    assert (np.abs(a.solution - b.solution) <= 1e-9 * scale).all()
+    assert (np.abs(a.solution - b.solution) <= 1e-5 * scale).all()
     a.check_failures()
     bad = a.solution
     bad[5, 3, 3] = -1.0
