@@ -35,7 +35,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # Algorithmic bytes per zone: a stage reads p and writes p' (NCONS fp64 each); a stage
 # with a != 0 also reads the u^n source at the zone centre.  RK2 zone-update = one of each.
-NCONS = {"iso": 3, "gam": 4}
+NCONS = {"iso": 3, "gam": 4, "srhd": 4}
+# srhd_2d (first cut, reference data flow): per RK stage conserved_to_primitive reads u, p-guess and writes
+# u', p (4 arrays) and advance_rk reads u^n, p, u and writes u' (4 arrays): 8 x 32 B, plus the 64 B copy of
+# new_iteration once per step.
+SRHD_BYTES_PER_ZONE_UPDATE = 2 * 8 * 32.0 + 64.0
 
 
 def parse_args():
@@ -44,7 +48,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--resolution", type=int, default=None, help="zones per side (default 4096*sqrt(gpus))")
-    ap.add_argument("--solver", default="iso", choices=["iso", "gam"])
+    ap.add_argument("--solver", default="iso", choices=["iso", "gam", "srhd"])
     ap.add_argument("--unfused", action="store_true", help="drive the reference-named kernels in reference order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
@@ -58,14 +62,14 @@ def default_resolution(gpus):
     return int(n // 8) * 8
 
 
-def cpu_baseline(setup_kwargs, resolution, target_seconds):
+def cpu_baseline(setup_name, setup_kwargs, resolution, target_seconds):
     """Time the reference's CPU path (or our port of it) on a few steps of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as test_oracle
     import ref_solver
     from sailfish_amd.setups import make_setup
 
-    setup = make_setup("circumbinary-disk", **setup_kwargs)
+    setup = make_setup(setup_name, **setup_kwargs)
     mesh = setup.mesh(resolution)
     lib = test_oracle.ref(setup.solver, "omp")
     kind = "reference"
@@ -73,11 +77,21 @@ def cpu_baseline(setup_kwargs, resolution, target_seconds):
         lib = test_oracle.oracle()
         kind = "port"
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
-    solver = ref_solver.OracleSolver(setup, mesh, time=0.0, lib=lib)
-    cfl = 0.3 if setup.solver == "cbdiso_2d" else 0.1
+    if setup.solver == "srhd_2d":
+        # the reference's solver loop is our host mirror of it (pinned bitwise by tests/test_srhd_solver.py)
+        # on the reference's own C kernels
+        from oracle_backend import OracleBackend
+        from sailfish_amd.solvers import make_solver
+
+        solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=setup.start_time,
+                             backend=OracleBackend(lib), distributed=False)
+        cfl = 0.4
+    else:
+        solver = ref_solver.OracleSolver(setup, mesh, time=0.0, lib=lib)
+        cfl = 0.3 if setup.solver == "cbdiso_2d" else 0.1
 
     def step():
-        dt = mesh.min_spacing() / solver.maximum_wavespeed() * cfl
+        dt = mesh.min_spacing(solver.time) / solver.maximum_wavespeed() * cfl
         solver.advance(dt)
 
     step()  # warm-up (page faults, OpenMP team start)
@@ -94,8 +108,8 @@ def cpu_baseline(setup_kwargs, resolution, target_seconds):
         unit="Mzps",
         cores=cores,
         kind=kind,
-        sample=f"{n} RK2 steps (p2c + set_bc + 2 advance_rk + wavespeed/max, reference order) of the "
-               f"{resolution}^2 circumbinary-disk workload, OpenMP on {cores} threads, {seconds:.1f} s",
+        sample=f"{n} RK2 steps (reference order of kernels and set_bc) of the {setup_name} workload at resolution "
+               f"{resolution} ({mesh.shape[0]} x {mesh.shape[1]} zones), OpenMP on {cores} threads, {seconds:.1f} s",
     )
 
 
@@ -119,12 +133,21 @@ def main():
     from sailfish_amd.setups import make_setup
     from sailfish_amd.solvers import make_solver
 
-    resolution = args.resolution or default_resolution(args.gpus)
-    setup_kwargs = dict(eos="isothermal" if args.solver == "iso" else "gamma-law")
-    setup = make_setup("circumbinary-disk", **setup_kwargs)
+    if args.solver == "srhd":
+        # BASELINE.json configs[4]: the reference's own srhd_2d problem, a relativistic shell in a homologous
+        # envelope on an expanding log-spherical mesh; 4800 zones per decade = 4800 x 3273 zones on one GPU
+        setup_name, setup_kwargs = "envelope-shock", dict(polar_extent=0.5)
+        resolution = args.resolution or int(4800 * math.sqrt(args.gpus))
+        extra = {}
+    else:
+        setup_name = "circumbinary-disk"
+        resolution = args.resolution or default_resolution(args.gpus)
+        setup_kwargs = dict(eos="isothermal" if args.solver == "iso" else "gamma-law")
+        extra = dict(fused=not args.unfused)
+    setup = make_setup(setup_name, **setup_kwargs)
     mesh = setup.mesh(resolution)
-    solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0,
-                         num_patches=world, mode="hip", fused=not args.unfused)
+    solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=setup.start_time,
+                         num_patches=world, mode="hip", **extra)
     cfl = solver.recommended_cfl
 
     def step():
@@ -142,7 +165,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    use_events = not args.no_events and not args.unfused
+    use_events = not args.no_events and not args.unfused and args.solver != "srhd"
     if use_events:
         solver.event_log = []
     fence()
@@ -161,6 +184,8 @@ def main():
     BYTES_STAGE_NO_UN = 2 * 8.0 * NCONS[args.solver]
     BYTES_STAGE_UN = 3 * 8.0 * NCONS[args.solver]
     BYTES_PER_ZONE_UPDATE = BYTES_STAGE_NO_UN + BYTES_STAGE_UN
+    if args.solver == "srhd":
+        BYTES_PER_ZONE_UPDATE = SRHD_BYTES_PER_ZONE_UPDATE
 
     roofline = None
     kernel_ms = None
@@ -198,14 +223,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(setup_kwargs, resolution, args.cpu_seconds)
+            cpu = cpu_baseline(setup_name, setup_kwargs, resolution, args.cpu_seconds)
         except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
             cpu = dict(value=None, unit="Mzps", cores=0, kind="port", sample=f"failed: {exc!r}")
 
     if rank == 0:
         bytes_per_update = BYTES_PER_ZONE_UPDATE
         line = {
-            "metric": "zone-updates/sec (Mzps) fp64, cbdiso_2d" if args.solver == "iso" else "zone-updates/sec (Mzps) fp64, cbdgam_2d",
+            "metric": f"zone-updates/sec (Mzps) fp64, {setup.solver}",
             "value": round(mzps, 2),
             "unit": "Mzps",
             "n_gpus": world,
@@ -218,11 +243,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{setup.solver} circumbinary-disk {resolution}^2 fp64, RK2, "
+                "workload": f"{setup.solver} {setup_name} {mesh.shape[0]}x{mesh.shape[1]} fp64, RK2, "
                             f"{world} slab patch(es), one per GPU; dt recomputed every step",
                 "zones": zones,
                 "zones_per_gpu": zones // world,
-                "path": "reference-order kernels" if args.unfused else "fused stage kernels",
+                "path": "reference-order kernels" if (args.unfused or args.solver == "srhd") else "fused stage kernels",
             },
             "hbm_roofline_frac_whole_step": round(mzps * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline,

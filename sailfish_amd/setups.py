@@ -418,12 +418,12 @@ class EnvelopeShock(Setup):
         (r, t), envelope_shock.py:243), the polar profile once per column; same scalar calls, same bits."""
         nj = mesh.shape[1]
         out = np.zeros([i1 - i0, nj, 4])
-        polar = [self.shell_u_profile_polar(mesh.cell_coordinates(t, 0, j)[1]) for j in range(nj)]
+        polar = np.array([self.shell_u_profile_polar(mesh.cell_coordinates(t, 0, j)[1]) for j in range(nj)])
         for i in range(i0, i1):
             m, d, u, p = self.envelope_state(mesh.cell_coordinates(t, i, 0)[0], t)
             du = self.shell_u_profile_mass(m)
             out[i - i0, :, 0] = d
-            out[i - i0, :, 1] = [u + du * f for f in polar]
+            out[i - i0, :, 1] = u + du * polar  # elementwise: the same multiply and add per zone
             out[i - i0, :, 3] = p
         return out
 

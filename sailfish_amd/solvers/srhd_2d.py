@@ -306,12 +306,14 @@ class Solver(SolverBase):
         """
         The reference copies halos with periodic wrap-around (srhd_2d.py:349-357) and then overwrites
         the domain ends for outflow / inflow / reflect; the other modes (jet, fixed, periodic) keep the
-        wrapped rows, so the wrap is only skipped where it would be overwritten anyway.
+        wrapped rows.  The wrap link is skipped only when both ends would overwrite it (a link has to
+        exist on both of its sides or on neither).
         """
         n = self.num_patches
         bcl, bcr = self.boundary_condition
-        lower = k - 1 if k > 0 else (None if bcl in FILLED_BY_SET_BC else n - 1)
-        upper = k + 1 if k < n - 1 else (None if bcr in FILLED_BY_SET_BC else 0)
+        wrap = bcl not in FILLED_BY_SET_BC or bcr not in FILLED_BY_SET_BC
+        lower = k - 1 if k > 0 else (n - 1 if wrap else None)
+        upper = k + 1 if k < n - 1 else (0 if wrap else None)
         return lower, upper
 
     def set_bc(self, array):

@@ -55,8 +55,10 @@ def _np(t):
 
 
 class OracleLibrary:
-    def __init__(self):
-        self.orc = _oracle.oracle()
+    def __init__(self, orc=None):
+        # `orc` may also be one of the compiled-reference libraries (oracle.ref): the reference-named
+        # kernels then come from the reference's own C (used by bench.py's cpu_baseline for srhd_2d)
+        self.orc = orc or _oracle.oracle()
 
     def __getattr__(self, name):
         if name in _oracle.API:
@@ -128,11 +130,15 @@ class OracleLibrary:
     def _sfhip_srhd_2d_set_macros(self, shape, kw, args):
         import ctypes
 
+        if self.orc.prefix != "sfo_":  # a compiled reference: its macros are fixed at build time
+            if (kw["plm_theta"], kw["mach_ceiling"]) != (1.5, 1e6):
+                raise ValueError("the compiled reference srhd_2d library was built with the default macros")
+            return
         self.orc.dll.sfo_srhd_2d_set_macros.argtypes = [ctypes.c_double] * 2
         self.orc.dll.sfo_srhd_2d_set_macros(kw["plm_theta"], kw["mach_ceiling"])
 
     def _sfhip_srhd_2d_failures(self, shape, kw, args):
-        kw["out"][0] = float(self.orc.dll.sfo_srhd_2d_failures())
+        kw["out"][0] = float(self.orc.dll.sfo_srhd_2d_failures()) if self.orc.prefix == "sfo_" else 0.0
 
     def _sfhip_timestep(self, shape, kw, args):
         with np.errstate(divide="ignore"):  # amax == 0 gives inf on the device too
@@ -206,8 +212,8 @@ class OracleLibrary:
 class OracleBackend:
     mode = "host"
 
-    def __init__(self):
-        self.lib = OracleLibrary()
+    def __init__(self, orc=None):
+        self.lib = OracleLibrary(orc)
         self.xp = get_array_module("host")
 
     def context(self, device_id):
