@@ -29,6 +29,7 @@ on rank ``k * world // num_patches``; halo slabs between ranks travel as
 ``isend``/``irecv`` pairs on a side stream while the rows that do not depend on
 them are updated, and dt is a MAX all-reduce of one double.
 """
+import contextlib
 from logging import getLogger
 
 import numpy as np
@@ -295,6 +296,7 @@ class SolverBase:
         self._wavespeed_floor = 0.0
         self._dt_dev = None
         self._fetch_stream = None
+        self._remote_neighbors = None
         self.event_log = None  # bench.py sets this to a list to time every stage launch with HIP events
 
     def _patch_kwargs(self):
@@ -470,6 +472,15 @@ class SolverBase:
             return
 
         last_stage = stage == nstages - 1
+        # With halos from other ranks (device runs): the rows that need them are updated on the comm
+        # stream, right behind the receives, concurrently with the interior launch on the compute
+        # stream -- neither the halo latency nor the thin boundary launches sit on the critical path.
+        side = self.backend.mode == "hip" and self._has_remote_neighbors()
+        if side and last_stage:
+            # the wavespeed fold is then shared by launches on two streams: reset it before either starts
+            for p in self.patches:
+                with p.execution_context:
+                    p.wavespeed_max.zero_()
         pending = self.start_halo_exchange()
         plans = []
         for p in self.patches:
@@ -481,22 +492,34 @@ class SolverBase:
             next_masses = self.point_masses(p.stage_time(rk_param, dt)) if last_stage else masses
             plans.append((p, lo, hi, rd, un, wr, masses, next_masses))
             with p.execution_context:
-                self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, lo, hi, 2 if last_stage else 0,
-                             dt_device)
-        self.finish_halo_exchange(pending)
+                self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, lo, hi,
+                             (1 if side else 2) if last_stage else 0, dt_device)
+        self.finish_halo_exchange(pending, join=not side)
+        torch = self._torch() if side else None
         for p, lo, hi, rd, un, wr, masses, next_masses in plans:
             ni = p.shape[0]
             with p.execution_context:
-                if lo > 0:
-                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, 0, lo, 1 if last_stage else 0,
-                                 dt_device)
-                if hi < ni:
-                    self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, hi, ni, 1 if last_stage else 0,
-                                 dt_device)
+                stream = torch.cuda.stream(self._comm_stream) if side else contextlib.nullcontext()
+                with stream:
+                    if lo > 0:
+                        self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, 0, lo,
+                                     1 if last_stage else 0, dt_device)
+                    if hi < ni:
+                        self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, hi, ni,
+                                     1 if last_stage else 0, dt_device)
+                if side:
+                    torch.cuda.current_stream().wait_stream(self._comm_stream)  # the stage is complete on both
             if dt_device is None:
                 p.finish_stage(rk_param, dt, wr)
             p.wavespeed_valid = last_stage
         return [plan[5] for plan in plans]
+
+    def _has_remote_neighbors(self):
+        if self._remote_neighbors is None:
+            local = set(self.local_ids)
+            self._remote_neighbors = any(
+                n is not None and n not in local for k in self.local_ids for n in self._neighbors(k))
+        return self._remote_neighbors
 
     def step(self, cfl_number, dx=None):
         """
@@ -653,7 +676,8 @@ class SolverBase:
             return reqs
         return dist.batch_isend_irecv(p2p)
 
-    def finish_halo_exchange(self, reqs):
+    def finish_halo_exchange(self, reqs, join=True):
+        """Wait for the halos on the comm stream; with `join` the compute stream then waits for it too."""
         if not reqs:
             return
         if self.backend.mode == "hip":
@@ -662,7 +686,8 @@ class SolverBase:
                 with torch.cuda.stream(self._comm_stream):
                     for r in reqs:
                         r.wait()
-                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                if join:
+                    torch.cuda.current_stream().wait_stream(self._comm_stream)
         else:
             for r in reqs:
                 r.wait()
