@@ -343,4 +343,181 @@ __global__ __launch_bounds__(256) void srhd_advance_kernel(SrhdParams P, const d
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// srhd_2d_advance_rk as marching waves (the design of the cbd stage kernels, sf_iso.hpp): one wave
+// owns 64 columns in j (60 outputs + 2 halo lanes per side, columns clamped to [0, nj) exactly as
+// the reference clamps its j-neighbours, srhd_2d.c:666-669) and marches down a chunk of rows.  Slopes
+// are evaluated once per zone and each HLLC flux once per face -- the thread-per-zone kernel above, like
+// the reference, evaluates every face twice -- with the same IEEE operations, so the result is still
+// bit-identical.  One subtlety: `num_first_order_zones` zeroes the slopes by the index of the zone that
+// LOOKS at a face (srhd_2d.c:694-702), so the face between rows nfo-1 and nfo is seen differently from
+// its two sides; that one row of faces is evaluated twice here as well.
+// grid: 1-D, 256 threads = 4 waves; wave w owns strip (w % nstrips) and row chunk (w / nstrips).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void srhd_march_kernel(SrhdParams P, const double *__restrict__ cons_rk,
+                                                            const double *__restrict__ prim_rd,
+                                                            const double *__restrict__ cons_rd,
+                                                            double *__restrict__ cons_wr,
+                                                            int rows_per_chunk, int nstrips, int nchunks)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int strip = gw % nstrips;
+    const int chunk = gw / nstrips;
+    if (chunk >= nchunks) return;
+
+    const int ni = P.ni, nj = P.nj;
+    const long si = 4L * nj;
+    const int Jraw = strip * STRIP + lane - HALO;                   // column this lane stands for
+    const int J = Jraw < 0 ? 0 : (Jraw > nj - 1 ? nj - 1 : Jraw);   // where it loads from (polar clamp)
+    const bool store_lane = lane >= HALO && lane < WAVE - HALO && Jraw < nj;
+    const long col = (long)J * 4;
+    // Lanes standing for columns outside [0, nj) hold copies of the edge zone's state (the reference's
+    // clamped neighbours), but their faces are where they stand: the lane for column nj has its lower
+    // face at the polar angle of face nj -- the edge zone's upper face, whose flux it supplies.
+    const double q0 = P.dq * (J + 0), q1 = P.dq * (J + 1);
+    const double qc = 0.5 * (q0 + q1);
+    const int f0 = Jraw < 0 ? 0 : (Jraw > nj ? nj : Jraw), f1 = Jraw + 1 < 0 ? 0 : (Jraw + 1 > nj ? nj : Jraw + 1);
+    const double s0 = P.sinq[f0], s1 = P.sinq[f1], c0 = P.cosq[f0], c1 = P.cosq[f1];
+    const double dcosq = c1 - c0, dsinq = s1 - s0;
+    const double sfac = P.a0 + P.adot * P.time;
+    const bool jet_on = P.jet_mdot > 0.0;
+    const int nfo = P.num_first_order_zones;
+
+    // zone rows [i0, i1) of this chunk; array rows are zone rows + NG
+    const int i0 = chunk * rows_per_chunk;
+    int i1 = i0 + rows_per_chunk;
+    if (i1 > ni) i1 = ni;
+
+    double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4], pn[4];
+    double gyb[4] = {0, 0, 0, 0};       // y-slopes of row r-1 (already zeroed where first order)
+    double gxa[4] = {0, 0, 0, 0};       // x-slopes of row r-2, NOT zeroed (who looks decides, see above)
+    double Fp[4] = {0, 0, 0, 0};        // flux through the lower face of row r-2, as that row sees it
+    double GLp[4] = {0, 0, 0, 0};       // flj * da_q0 of row r-2
+    double GUp[4] = {0, 0, 0, 0};       // frj * da_q1 of row r-2
+    {
+        const double *src = prim_rd + (long)(i0 - 2 + NG) * si + col;
+        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+    }
+    // r = zone row whose primitives arrive this iteration; row r-1 gets its x-slopes and faces,
+    // row r-2 is updated
+    for (int r = i0 - 2; r <= i1 + 1; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pc[q] = pn[q];
+        if (r < i1 + 1) {
+            const double *src = prim_rd + (long)(r + 1 + NG) * si + col;
+            pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+        }
+        // y-slopes of row r (neighbouring lanes hold the clamped neighbours)
+        double gyc[4];
+        const bool so_c = r >= nfo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double g = sr_slope(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]), P.theta);
+            gyc[q] = so_c ? g : 0.0;
+        }
+        if (r >= i0) {
+            const int ib = r - 1;       // zone row of pb
+            const bool so_b = ib >= nfo;
+            double gxb[4];              // x-slopes of row r-1, not zeroed
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gxb[q] = sr_slope(pa[q], pb[q], pc[q], P.theta);
+
+            const double xlo = P.faces[ib < 0 ? 0 : (ib > ni ? ni : ib)];   // lower face of row r-1 (clamped: unused when out of range)
+            const double rlo = xlo * sfac;
+            double Fup[4] = {0, 0, 0, 0};   // face between rows r-2 and r-1 as row r-2 sees it (its upper face)
+            double Flo[4] = {0, 0, 0, 0};   // ... as row r-1 sees it (its lower face)
+            if (r >= i0 + 1) {
+                // The left state uses row r-2's slopes, the right state row r-1's; whether they count is
+                // decided by the viewing zone (see header).  The two views differ only when ib == nfo.
+                double pl[4], pr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pl[q] = pa[q] + 0.5 * (so_b ? gxa[q] : 0.0);
+                    pr[q] = pb[q] - 0.5 * (so_b ? gxb[q] : 0.0);
+                }
+                sr_hllc<1>(pl, pr, xlo * P.adot, Flo);
+                if (ib == nfo && ib > 0) {
+                    // row r-2 < nfo looks at this face without slopes (p +- 0.5 * 0, literally)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pl[q] = pa[q] + 0.5 * 0.0;
+                        pr[q] = pb[q] - 0.5 * 0.0;
+                    }
+                    sr_hllc<1>(pl, pr, xlo * P.adot, Fup);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Fup[q] = Flo[q];
+                }
+            }
+            double GL[4] = {0, 0, 0, 0}, GU[4] = {0, 0, 0, 0};
+            if (ib >= i0 && ib < i1) {
+                // polar face below this lane's zone in row r-1; radii of the row
+                const double rhi = P.faces[ib + 1] * sfac;
+                double pl[4], pr[4], G[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pl[q] = from_lane_below(pb[q] + 0.5 * gyb[q]);
+                    pr[q] = pb[q] - 0.5 * gyb[q];
+                }
+                sr_hllc<2>(pl, pr, 0.0, G);
+                const double a_q0 = sr_area(rlo, rhi, s0, c0, s0, c0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    GL[q] = G[q] * a_q0;              // flj * da_q0
+                    GU[q] = from_lane_above(GL[q]);   // frj * da_q1: the upper face is the lower face of lane j+1
+                }
+            }
+            const int iu = r - 2;       // zone row updated now (pa)
+            if (iu >= i0) {
+                const double x0 = P.faces[iu], x1 = P.faces[iu + 1];
+                const double r0 = x0 * sfac, r1 = x1 * sfac;
+                const long c = (long)(iu + NG) * si + (long)J * 4;
+                if (iu == 0 && jet_on) {
+                    // srhd_2d.c:642-655: jet inflow zone, or the innermost zone held fixed
+                    if (qc < P.jet_theta * 2.0 && P.time < 1.0 + P.jet_duration && store_lane) {
+                        double ju = P.jet_gamma_beta;
+                        double jrho = P.jet_mdot / (4.0 * SR_PI * r0 * r0 * ju);
+                        double prof = exp(-pow(qc / P.jet_theta, 2.0));
+                        double pj[4] = {jrho, ju * prof, 0.0, 1e-6 * jrho}, u[4];
+                        sr_p2c(pj, u, sr_volume(r0, r1, c0, c1));
+                        cons_wr[c] = u[0]; cons_wr[c + 1] = u[1]; cons_wr[c + 2] = u[2]; cons_wr[c + 3] = u[3];
+                    }
+                } else {
+                    const double a_r0 = sr_area(r0, r0, s0, c0, s1, c1), a_r1 = sr_area(r1, r1, s0, c0, s1, c1);
+                    // geometric_source_terms, srhd_2d.c:473-499 (u_phi = 0)
+                    const double ur = pa[1], uq = pa[2], up = 0.0, pg = pa[3];
+                    const double rhoh = sr_rho_h(pa);
+                    const double dr2 = r1 * r1 - r0 * r0;
+                    double src[4];
+                    src[0] = 0.0;
+                    src[1] = -SR_PI * dr2 * dcosq * (rhoh * (uq * uq + up * up) + 2 * pg);
+                    src[2] = +SR_PI * dr2 * (dcosq * rhoh * ur * uq + dsinq * (pg + rhoh * up * up));
+                    src[3] = 0.0;
+                    if (store_lane) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // fli*da_r0 - fri*da_r1 + flj*da_q0 - frj*da_q1 + sources, in the reference's order
+                            double v = cons_rd[c + q] +
+                                       (Fp[q] * a_r0 - Fup[q] * a_r1 + GLp[q] - GUp[q] + src[q]) * P.dt;
+                            cons_wr[c + q] = (1.0 - P.rk_param) * v + P.rk_param * cons_rk[c + q];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gxa[q] = gxb[q];
+                Fp[q] = Flo[q];
+                GLp[q] = GL[q];
+                GUp[q] = GU[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gyb[q] = gyc[q]; pa[q] = pb[q]; pb[q] = pc[q]; }
+    }
+}
+
 } // namespace sf

@@ -793,9 +793,20 @@ int srhd_2d_advance_rk(int ni, int nj, double *face_positions, double *conserved
     P.a0 = a0; P.adot = adot; P.time = time; P.rk_param = rk_param; P.dt = dt;
     P.jet_mdot = jet_mdot; P.jet_gamma_beta = jet_gamma_beta; P.jet_theta = jet_theta; P.jet_duration = jet_duration;
     P.num_first_order_zones = num_first_order_zones;
-    dim3 block(256), grid((nj + 255) / 256, ni);
-    hipLaunchKernelGGL(sf::srhd_advance_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
-                       conserved_wr);
+    if (env_int("SFHIP_SRHD_ZONE_KERNEL", 0)) { // thread-per-zone form (every face twice), kept for A/B timing
+        dim3 block(256), grid((nj + 255) / 256, ni);
+        hipLaunchKernelGGL(sf::srhd_advance_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd,
+                           conserved_rd, conserved_wr);
+        return check_launch("srhd_2d_advance_rk");
+    }
+    const int nstrips = (nj + sf::STRIP - 1) / sf::STRIP;
+    int rows_per_chunk, nchunks;
+    plan_rows(ni, nstrips, &rows_per_chunk, &nchunks);
+    const long waves = (long)nstrips * nchunks;
+    const int wpb = 4;
+    dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(sf::srhd_march_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
+                       conserved_wr, rows_per_chunk, nstrips, nchunks);
     return check_launch("srhd_2d_advance_rk");
 }
 

@@ -202,4 +202,6 @@ def srhd_branch_matrix():
         dict(ni=3, nj=2),
         dict(ni=1, nj=1),
         dict(polar_extent=0.5 * np.pi, nj=33, ni=9),
+        dict(ni=75, nj=130, num_first_order_zones=40, adot=0.1),   # several column strips and row chunks
+        dict(ni=40, nj=61, jet=True, time=1.5),                    # a strip holding a single column
     ]
