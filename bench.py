@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
     ap.add_argument("--sync-dt", action="store_true", help="dt = dx/maximum_wavespeed()*cfl; advance(dt) as two blocking calls")
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--strong", action="store_true",
+                    help="hold the MESH at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
     return ap.parse_args()
 
 
@@ -141,7 +143,7 @@ def main():
         extra = {}
     else:
         setup_name = "circumbinary-disk"
-        resolution = args.resolution or default_resolution(args.gpus)
+        resolution = args.resolution or (4096 if args.strong else default_resolution(args.gpus))
         setup_kwargs = dict(eos="isothermal" if args.solver == "iso" else "gamma-law")
         extra = dict(fused=not args.unfused)
     setup = make_setup(setup_name, **setup_kwargs)
@@ -238,7 +240,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(seconds / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.strong or args.resolution) and world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
