@@ -105,13 +105,19 @@ def cpu_baseline(setup_name, setup_kwargs, resolution, target_seconds):
     for _ in range(n):
         step()
     seconds = time.perf_counter() - t0
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return dict(
         value=mesh.num_total_zones * n / seconds * 1e-6,
         unit="Mzps",
         cores=cores,
         kind=kind,
         sample=f"{n} RK2 steps (reference order of kernels and set_bc) of the {setup_name} workload at resolution "
-               f"{resolution} ({mesh.shape[0]} x {mesh.shape[1]} zones), OpenMP on {cores} threads, {seconds:.1f} s",
+               f"{resolution} ({mesh.shape[0]} x {mesh.shape[1]} zones), OpenMP on {cores} threads of {model}, {seconds:.1f} s",
     )
 
 

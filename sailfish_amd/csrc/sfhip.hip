@@ -684,8 +684,8 @@ int srhd_state(int nj, double polar_extent, SrhdDeviceState **out)
     }
     if (st.nj != nj || memcmp(&st.polar_extent, &polar_extent, sizeof(double)) != 0) {
         if (st.trig) {
-            hipDeviceSynchronize(); // kernels of an earlier mesh may still be reading the old table
-            hipFree(st.trig);
+            (void)hipDeviceSynchronize(); // kernels of an earlier mesh may still be reading the old table
+            (void)hipFree(st.trig);
             st.trig = nullptr;
             st.nj = -1;
         }
