@@ -67,12 +67,16 @@ def test_reductions_full_size_properties():
         Diagnostic("torque", gravity=True, which_mass=2), Diagnostic("angular_momentum"),
     ]
     physics = dict(setup.physics, diagnostics=diagnostics)
-    results = []
+    results, states = [], []
     for num_patches in (1, 4):
         s = make_solver(setup.solver, physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=num_patches,
                         mode="hip")
-        s.step(0.3)
+        dts = [s.step(0.3) for _ in range(2)]
         results.append(np.array(s.reductions()))
+        states.append((dts, s.solution))
+    # the update itself at the bench size: slab decomposition changes neither dt nor a single bit of the state
+    assert states[0][0] == states[1][0]
+    assert np.array_equal(states[0][1], states[1][1])
     one, four = results
     assert np.allclose(one, four, rtol=1e-11, atol=1e-13)
     m, m_in, m_out, md, md1, md2, tq, tq1, tq2, lz = one
