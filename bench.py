@@ -36,10 +36,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 # Algorithmic bytes per zone: a stage reads p and writes p' (NCONS fp64 each); a stage
 # with a != 0 also reads the u^n source at the zone centre.  RK2 zone-update = one of each.
 NCONS = {"iso": 3, "gam": 4, "srhd": 4}
-# srhd_2d (first cut, reference data flow): per RK stage conserved_to_primitive reads u, p-guess and writes
-# u', p (4 arrays) and advance_rk reads u^n, p, u and writes u' (4 arrays): 8 x 32 B, plus the 64 B copy of
-# new_iteration once per step.
-SRHD_BYTES_PER_ZONE_UPDATE = 2 * 8 * 32.0 + 64.0
+# srhd_2d, fused stages (sfhip_srhd_2d_stage): a stage reads the primitives and the conserved state (and u^n
+# when rk_param != 0) and writes the updated state, its floored copy and its primitives: 5 or 6 arrays of 32 B
+# per zone; RK2 zone-update = 11 x 32 B.  (The reference's sequence moves 18 arrays: 576 B.)
+SRHD_BYTES_PER_ZONE_UPDATE = 11 * 32.0
 
 
 def parse_args():
@@ -146,7 +146,7 @@ def main():
         # envelope on an expanding log-spherical mesh; 4800 zones per decade = 4800 x 3273 zones on one GPU
         setup_name, setup_kwargs = "envelope-shock", dict(polar_extent=0.5)
         resolution = args.resolution or int(4800 * math.sqrt(args.gpus))
-        extra = {}
+        extra = dict(fused=not args.unfused)
     else:
         setup_name = "circumbinary-disk"
         resolution = args.resolution or (4096 if args.strong else default_resolution(args.gpus))
@@ -255,7 +255,7 @@ def main():
                             f"{world} slab patch(es), one per GPU; dt recomputed every step",
                 "zones": zones,
                 "zones_per_gpu": zones // world,
-                "path": "reference-order kernels" if (args.unfused or args.solver == "srhd") else "fused stage kernels",
+                "path": "reference-order kernels" if args.unfused else "fused stage kernels",
             },
             "hbm_roofline_frac_whole_step": round(mzps * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline,

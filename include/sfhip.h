@@ -622,6 +622,34 @@ SFHIP_API int srhd_2d_advance_rk(
     int num_first_order_zones)
 ;
 
+/* Fused srhd_2d stage: srhd_2d_advance_rk (srhd_2d.c:616-749) followed, zone by zone while the
+ * updated state is still in registers, by the srhd_2d_conserved_to_primitive call (srhd_2d.c:544-575)
+ * with which the reference opens the NEXT stage (Solver.advance_rk, srhd_2d.py:339-341):
+ * conserved_wr receives the updated state as advance_rk leaves it, conserved_floored and
+ * primitive_wr what conserved_to_primitive would then write into conserved2 / primitive
+ * (guess: primitive_rd[..., 3] of the zone; volume at scale_factor_next).  Removes the
+ * recovery pass (128 B per zone, HBM-bound).  Not for patches with the jet boundary
+ * (jet_mdot > 0 is refused: zones the reference leaves unwritten keep stale data there). */
+SFHIP_API int sfhip_srhd_2d_stage(
+    int ni,
+    int nj,
+    double *face_positions, // :: $.shape == (ni + 1,)
+    double *conserved_rk, // :: $.shape == (ni + 4, nj, 4)
+    double *primitive_rd, // :: $.shape == (ni + 4, nj, 4)
+    double *conserved_rd, // :: $.shape == (ni + 4, nj, 4)
+    double *conserved_wr, // :: $.shape == (ni + 4, nj, 4)
+    double polar_extent,
+    double a0,
+    double adot,
+    double time,
+    double rk_param,
+    double dt,
+    int num_first_order_zones,
+    double scale_factor_next, // :: $ >= 0.0
+    double *primitive_wr, // :: $.shape == (ni + 4, nj, 4)
+    double *conserved_floored) // :: $.shape == (ni + 4, nj, 4)
+;
+
 /* Number of zones for which srhd_2d_conserved_to_primitive hit one of the reference's
  * fatal conditions since the last call (device counter read back: synchronises).
  * out[0] receives the count; n must be 1. */

@@ -29,6 +29,13 @@ struct SrhdParams {
     double a0, adot, time, rk_param, dt;
     double jet_mdot, jet_gamma_beta, jet_theta, jet_duration;
     int num_first_order_zones;
+    // fused stage (sfhip_srhd_2d_stage): the primitive recovery that the reference runs at the start of the
+    // NEXT stage is done here, on the zone just updated, while it is still in registers
+    int fuse_c2p;
+    double scale_factor_next;      // scale factor at the time after this stage
+    double *prim_wr;               // (ni + 4, nj, 4) primitives of the updated state (interior rows)
+    double *cons_floored;          // (ni + 4, nj, 4) updated state after the Mach-ceiling floor
+    unsigned int *failures;
     const double *faces;   // (ni + 1) comoving radial face positions
     const double *sinq;    // (nj + 1) sin of the polar face angles dq * j, from the host's libm
     const double *cosq;    // (nj + 1)
@@ -497,12 +504,26 @@ __global__ __launch_bounds__(256, 2) void srhd_march_kernel(SrhdParams P, const 
                     src[2] = +SR_PI * dr2 * (dcosq * rhoh * ur * uq + dsinq * (pg + rhoh * up * up));
                     src[3] = 0.0;
                     if (store_lane) {
+                        double un[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             // fli*da_r0 - fri*da_r1 + flj*da_q0 - frj*da_q1 + sources, in the reference's order
                             double v = cons_rd[c + q] +
                                        (Fp[q] * a_r0 - Fup[q] * a_r1 + GLp[q] - GUp[q] + src[q]) * P.dt;
-                            cons_wr[c + q] = (1.0 - P.rk_param) * v + P.rk_param * cons_rk[c + q];
+                            un[q] = (1.0 - P.rk_param) * v + P.rk_param * cons_rk[c + q];
+                            cons_wr[c + q] = un[q];
+                        }
+                        if (P.fuse_c2p) {
+                            // srhd_2d_conserved_to_primitive of the next stage (srhd_2d.c:544-575): guess = this
+                            // zone's current pressure, volume at the next stage's scale factor
+                            double uf[4], pw[4] = {0.0, 0.0, 0.0, pa[3]};
+                            const double dvn = sr_volume(x0 * P.scale_factor_next, x1 * P.scale_factor_next, c0, c1);
+                            if (sr_c2p(un, uf, pw, dvn, P.mach_ceiling2)) atomicAdd(P.failures, 1u);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                P.prim_wr[c + q] = pw[q];
+                                P.cons_floored[c + q] = uf[q];
+                            }
                         }
                     }
                 }

@@ -778,14 +778,21 @@ int srhd_2d_max_wavespeeds(int ni, int nj, double *face_positions, double *primi
     return check_launch("srhd_2d_max_wavespeeds");
 }
 
-int srhd_2d_advance_rk(int ni, int nj, double *face_positions, double *conserved_rk, double *primitive_rd,
-                       double *conserved_rd, double *conserved_wr, double polar_extent, double a0, double adot,
-                       double time, double rk_param, double dt, double jet_mdot, double jet_gamma_beta,
-                       double jet_theta, double jet_duration, int num_first_order_zones)
+static int srhd_advance_impl(int ni, int nj, double *face_positions, double *conserved_rk, double *primitive_rd,
+                             double *conserved_rd, double *conserved_wr, double polar_extent, double a0, double adot,
+                             double time, double rk_param, double dt, double jet_mdot, double jet_gamma_beta,
+                             double jet_theta, double jet_duration, int num_first_order_zones,
+                             bool fuse, double scale_factor_next, double *primitive_wr, double *conserved_floored)
 {
     if (!conserved_rk || !primitive_rd || !conserved_rd || !conserved_wr) return fail(-1, "srhd_2d_advance_rk: null array");
     if (conserved_wr == conserved_rd || conserved_wr == conserved_rk)
         return fail(-1, "srhd_2d_advance_rk: conserved_wr must not alias an input");
+    if (fuse) {
+        if (!primitive_wr || !conserved_floored) return fail(-1, "sfhip_srhd_2d_stage: null output array");
+        if (primitive_wr == primitive_rd) return fail(-1, "sfhip_srhd_2d_stage: primitive_wr must not alias primitive_rd");
+        if (conserved_floored == conserved_rd || conserved_floored == conserved_rk || conserved_floored == conserved_wr)
+            return fail(-1, "sfhip_srhd_2d_stage: conserved_floored must not alias another conserved array");
+    }
     sf::SrhdParams P;
     SrhdDeviceState *st;
     int rc = srhd_fill(P, ni, nj, face_positions, polar_extent, &st);
@@ -793,7 +800,12 @@ int srhd_2d_advance_rk(int ni, int nj, double *face_positions, double *conserved
     P.a0 = a0; P.adot = adot; P.time = time; P.rk_param = rk_param; P.dt = dt;
     P.jet_mdot = jet_mdot; P.jet_gamma_beta = jet_gamma_beta; P.jet_theta = jet_theta; P.jet_duration = jet_duration;
     P.num_first_order_zones = num_first_order_zones;
-    if (env_int("SFHIP_SRHD_ZONE_KERNEL", 0)) { // thread-per-zone form (every face twice), kept for A/B timing
+    P.fuse_c2p = fuse ? 1 : 0;
+    P.scale_factor_next = scale_factor_next;
+    P.prim_wr = primitive_wr;
+    P.cons_floored = conserved_floored;
+    P.failures = st->failures;
+    if (!fuse && env_int("SFHIP_SRHD_ZONE_KERNEL", 0)) { // thread-per-zone form (every face twice), kept for A/B timing
         dim3 block(256), grid((nj + 255) / 256, ni);
         hipLaunchKernelGGL(sf::srhd_advance_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd,
                            conserved_rd, conserved_wr);
@@ -808,6 +820,26 @@ int srhd_2d_advance_rk(int ni, int nj, double *face_positions, double *conserved
     hipLaunchKernelGGL(sf::srhd_march_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
                        conserved_wr, rows_per_chunk, nstrips, nchunks);
     return check_launch("srhd_2d_advance_rk");
+}
+
+int srhd_2d_advance_rk(int ni, int nj, double *face_positions, double *conserved_rk, double *primitive_rd,
+                       double *conserved_rd, double *conserved_wr, double polar_extent, double a0, double adot,
+                       double time, double rk_param, double dt, double jet_mdot, double jet_gamma_beta,
+                       double jet_theta, double jet_duration, int num_first_order_zones)
+{
+    return srhd_advance_impl(ni, nj, face_positions, conserved_rk, primitive_rd, conserved_rd, conserved_wr,
+                             polar_extent, a0, adot, time, rk_param, dt, jet_mdot, jet_gamma_beta, jet_theta,
+                             jet_duration, num_first_order_zones, false, 0.0, nullptr, nullptr);
+}
+
+int sfhip_srhd_2d_stage(int ni, int nj, double *face_positions, double *conserved_rk, double *primitive_rd,
+                        double *conserved_rd, double *conserved_wr, double polar_extent, double a0, double adot,
+                        double time, double rk_param, double dt, int num_first_order_zones,
+                        double scale_factor_next, double *primitive_wr, double *conserved_floored)
+{
+    return srhd_advance_impl(ni, nj, face_positions, conserved_rk, primitive_rd, conserved_rd, conserved_wr,
+                             polar_extent, a0, adot, time, rk_param, dt, 0.0, 0.0, 0.0, 0.0,
+                             num_first_order_zones, true, scale_factor_next, primitive_wr, conserved_floored);
 }
 
 int sfhip_srhd_2d_failures(int n, double *out)

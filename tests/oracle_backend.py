@@ -137,6 +137,16 @@ class OracleLibrary:
         self.orc.dll.sfo_srhd_2d_set_macros.argtypes = [ctypes.c_double] * 2
         self.orc.dll.sfo_srhd_2d_set_macros(kw["plm_theta"], kw["mach_ceiling"])
 
+    def _sfhip_srhd_2d_stage(self, shape, kw, args):
+        """advance_rk, then the conserved_to_primitive call that opens the next stage (include/sfhip.h)."""
+        a = {k: (_np(v) if hasattr(v, "numpy") else v) for k, v in kw.items()}
+        self.orc.call("srhd_2d_advance_rk", shape, a["face_positions"], a["conserved_rk"], a["primitive_rd"],
+                      a["conserved_rd"], a["conserved_wr"], a["polar_extent"], a["a0"], a["adot"], a["time"],
+                      a["rk_param"], a["dt"], 0.0, 0.0, 0.0, 0.0, a["num_first_order_zones"])
+        a["primitive_wr"][NG:-NG] = a["primitive_rd"][NG:-NG]  # the pressure guess of every zone
+        self.orc.call("srhd_2d_conserved_to_primitive", shape, a["face_positions"], a["conserved_wr"],
+                      a["conserved_floored"], a["primitive_wr"], a["polar_extent"], a["scale_factor_next"])
+
     def _sfhip_srhd_2d_failures(self, shape, kw, args):
         kw["out"][0] = float(self.orc.dll.sfo_srhd_2d_failures()) if self.orc.prefix == "sfo_" else 0.0
 

@@ -50,11 +50,12 @@ def run(name, **solver_kwargs):
     return g, initial, np.array(dts), np.array(times), solver.solution, solver.primitive
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "reference-order"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_host_logic_with_oracle_kernels_reproduces_reference_bitwise(name):
+def test_host_logic_with_oracle_kernels_reproduces_reference_bitwise(name, fused):
     from oracle_backend import OracleBackend
 
-    g, initial, dts, times, final, prim = run(name, backend=OracleBackend(), distributed=False)
+    g, initial, dts, times, final, prim = run(name, backend=OracleBackend(), distributed=False, fused=fused)
     assert np.array_equal(initial, g["initial"])
     assert np.array_equal(dts, g["dt"]) and np.array_equal(times, g["time"])
     assert np.array_equal(final, g["final"])
@@ -80,9 +81,10 @@ def test_patch_count_does_not_change_the_result():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "reference-order"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_hip_solver_matches_reference_run(name):
-    g, initial, dts, times, final, prim = run(name, mode="hip")
+def test_hip_solver_matches_reference_run(name, fused):
+    g, initial, dts, times, final, prim = run(name, mode="hip", fused=fused)
     if "jet" not in name:
         assert np.array_equal(initial, g["initial"])
         assert np.array_equal(dts, g["dt"]) and np.array_equal(times, g["time"])
