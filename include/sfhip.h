@@ -658,6 +658,222 @@ SFHIP_API int sfhip_srhd_2d_failures(
     double *out) // :: $.numel() >= 1
 ;
 
+/* ---------------------------------------------------------------------------
+ * cbdisodg_2d -- third-order modal discontinuous-Galerkin variant of the isothermal
+ * binary-accretion solver.  State arrays are
+ * (ni + 2, nj + 2, 3, 3, 3): ONE guard zone per side, then conserved field q and the
+ * Legendre orders m (x), n (y); the scheme uses the six slots with m + n < 3.
+ * --------------------------------------------------------------------------- */
+
+/* Replaces cbdisodg_2d_slope_limit, cbdisodg_2d.c:498-605 (caller: Patch.slope_limit,
+ * cbdisodg_2d.py:211-230).  Copies every zone's 27 weights and, in troubled zones,
+ * zeroes the higher moments and replaces the two slopes by the reference's minmod
+ * value -- which its `int` return type (cbdisodg_2d.c:455) truncates to an integer;
+ * reproduced.  The mesh and point-mass arguments are unused there and here.  Bit-exact. */
+SFHIP_API int cbdisodg_2d_slope_limit(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double point_mass1_x, // point mass 1
+    double point_mass1_y,
+    double point_mass2_x, // point mass 2
+    double point_mass2_y,
+    double *weights1, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *weights2) // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+;
+
+/* Replaces cbdisodg_2d_advance_rk, cbdisodg_2d.c:607-983 (caller: Patch.advance_rk,
+ * cbdisodg_2d.py:232-285).  Writes the 18 used slots of each interior zone of weights2. */
+SFHIP_API int cbdisodg_2d_advance_rk(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double *weights0, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *weights1, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *weights2, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double buffer_surface_density,
+    double buffer_central_mass,
+    double buffer_driving_rate,
+    double buffer_outer_radius,
+    double buffer_onset_width,
+    int buffer_is_enabled,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double soundspeed2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double nu, // kinematic viscosity coefficient
+    double rk_param, // RK parameter
+    double dt, // timestep
+    double velocity_ceiling)
+;
+
+/* Replaces cbdisodg_2d_wavespeed, cbdisodg_2d.c:1108-1176 (caller: Patch.maximum_wavespeed,
+ * cbdisodg_2d.py:169-205).  Bit-exact. */
+SFHIP_API int cbdisodg_2d_wavespeed(
+    int ni, // mesh
+    int nj,
+    double patch_xl,
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double soundspeed2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double velocity_ceiling,
+    double *weights, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *wavespeed) // :: $.shape == (ni + 2, nj + 2)
+;
+
+/* cbdisodg_2d_wavespeed fused with the `self.wavespeeds.max()` that follows it
+ * (cbdisodg_2d.py:205): the maximum goes straight to *wavespeed_max (device scalar,
+ * overwritten).  Bit-exact. */
+SFHIP_API int sfhip_cbdisodg_2d_max_wavespeed(
+    int ni, // mesh
+    int nj,
+    double patch_xl,
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double soundspeed2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double x1, // point mass 1
+    double y1,
+    double mass1,
+    double softening_length1,
+    double x2, // point mass 2
+    double y2,
+    double mass2,
+    double softening_length2,
+    double velocity_ceiling,
+    double *weights, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *wavespeed_max) // :: $.numel() >= 1
+;
+
+/* cbdisodg_2d_slope_limit on rows [i_begin, i_end) with the outflow guard fill that
+ * precedes it in the reference (Solver.set_bc, cbdisodg_2d.py:511-544) folded in as
+ * index clamps: with clamp_j the j-neighbours beyond the patch are the edge zone itself,
+ * with clamp_lower_i / clamp_upper_i likewise for the first / last row (set these on the
+ * patches that touch the domain edge; other patches read their guard rows, filled by the
+ * halo exchange). */
+SFHIP_API int sfhip_cbdisodg_2d_limit(
+    int ni,
+    int nj,
+    double *weights1, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *weights2, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    int clamp_lower_i,
+    int clamp_upper_i,
+    int clamp_j,
+    int i_begin, // :: 0 <= $ <= ni
+    int i_end) // :: i_begin <= $ <= ni
+;
+
+/* cbdisodg_2d_advance_rk on rows [i_begin, i_end) with the same index clamps, the time
+ * step optionally taken from device memory (dt_device != NULL overrides dt: the step is
+ * launched before the host knows dt, sfhip_timestep) and, with want_wavespeed, the
+ * cbdisodg_2d_wavespeed + max of the UPDATED state (point masses at their next positions
+ * wx1..wrsoft2) folded into *wavespeed_max by an exact atomic max: 2 = zero it first,
+ * 1 = accumulate into it, 0 = off. */
+SFHIP_API int sfhip_cbdisodg_2d_stage(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double *weights0, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *weights1, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double *weights2, // :: $.shape == (ni + 2, nj + 2, 3, 3, 3)
+    double buffer_surface_density,
+    double buffer_central_mass,
+    double buffer_driving_rate,
+    double buffer_outer_radius,
+    double buffer_onset_width,
+    int buffer_is_enabled,
+    double x1, // point mass 1
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2, // point mass 2
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double soundspeed2, // equation of state
+    double mach_squared,
+    int eos_type,
+    double nu, // kinematic viscosity coefficient
+    double rk_param, // RK parameter
+    double dt, // timestep
+    double velocity_ceiling,
+    int clamp_lower_i,
+    int clamp_upper_i,
+    int clamp_j,
+    int i_begin, // :: 0 <= $ <= ni
+    int i_end, // :: i_begin <= $ <= ni
+    int want_wavespeed, // :: 0 <= $ <= 2
+    double wx1,
+    double wy1,
+    double wmass1,
+    double wsoftening_length1,
+    double wx2,
+    double wy2,
+    double wmass2,
+    double wsoftening_length2,
+    double *wavespeed_max, // :: $.numel() >= 1
+    double *dt_device) // :: $ is None or $.numel() >= 1
+;
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ import sys
 REFERENCE = os.environ.get("SAILFISH_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
-SOLVERS = ("cbdiso_2d", "cbdgam_2d", "srhd_2d")
+SOLVERS = ("cbdiso_2d", "cbdgam_2d", "srhd_2d", "cbdisodg_2d")
 FLAVOURS = {"cpu": ["-DEXEC_MODE=0"], "omp": ["-DEXEC_MODE=1", "-fopenmp"]}
 # srhd_2d takes PLM_THETA / MACH_CEILING as define_macros from its Solver (srhd_2d.py:225-233; defaults
 # srhd_2d.py:66-67).  Extra builds with other values pin the oracle's run-time settings.

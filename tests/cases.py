@@ -205,3 +205,92 @@ def srhd_branch_matrix():
         dict(ni=75, nj=130, num_first_order_zones=40, adot=0.1),   # several column strips and row chunks
         dict(ni=40, nj=61, jet=True, time=1.5),                    # a strip holding a single column
     ]
+
+
+# ---------------------------------------------------------------------------
+# cbdisodg_2d: weights arrays (ni + 2, nj + 2, 3, 3, 3), one guard zone per side
+# ---------------------------------------------------------------------------
+DG_USED = [(m, n) for m in range(3) for n in range(3) if m + n < 3]
+
+
+def dg_weights(seed, ni, nj, extent, rough=0.0, moments=0.05):
+    """
+    Seeded modal weights: smooth zone averages (sigma > 0, momenta of either sign) with random
+    higher moments of relative size `moments`; `rough` adds zone-to-zone noise to the averages so
+    that the troubled-cell indicator and the limiter's branches fire.  The three unused slots of
+    each field hold a sentinel so tests can see that they are carried along / left alone.
+    """
+    rng = np.random.default_rng(seed)
+    xl, xr, yl, yr = extent
+    x = xl + (np.arange(-1, ni + 1) + 0.5) * (xr - xl) / ni
+    y = yl + (np.arange(-1, nj + 1) + 0.5) * (yr - yl) / nj
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    w = np.full((ni + 2, nj + 2, 3, 3, 3), 77.0)
+    avg = np.empty((ni + 2, nj + 2, 3))
+    avg[..., 0] = 1.0 + 0.3 * np.sin(1.3 * X) * np.cos(0.7 * Y)
+    avg[..., 1] = avg[..., 0] * (0.5 * np.cos(0.9 * X + 0.2) - 0.2 * Y)
+    avg[..., 2] = avg[..., 0] * (0.4 * np.sin(0.5 * Y - 0.1) + 0.1 * X)
+    if rough:
+        avg *= 1.0 + rough * rng.uniform(-1.0, 1.0, avg.shape)
+    for m, n in DG_USED:
+        if m + n == 0:
+            w[..., m, n] = avg
+        else:
+            w[..., m, n] = moments * rng.uniform(-1.0, 1.0, avg.shape) * np.abs(avg[..., :1])
+    return w
+
+
+def dg_case(seed=0, ni=20, nj=28, eos=2, nu=0.001, buffer_on=True, sink_model=2, rk_param=0.0, masses=True,
+            extent=(-1.6, 1.6, -2.4, 2.4), sink_rate=10.0, dt=1e-3, rough=0.0, moments=0.05, big_slopes=False):
+    w1 = dg_weights(seed, ni, nj, extent, rough, moments)
+    w0 = dg_weights(seed + 500, ni, nj, extent, rough, moments)
+    if big_slopes:  # slopes beyond +-1 so that the limiter's integer truncation returns non-zero values
+        rng = np.random.default_rng(seed + 9)
+        w1[..., 1, 0] = rng.uniform(-6.0, 6.0, w1.shape[:3])
+        w1[..., 0, 1] = rng.uniform(-6.0, 6.0, w1.shape[:3])
+        w1[..., 0, 0] += rng.integers(-4, 5, w1.shape[:3]) * np.sqrt(3.0) * 2.5
+        w1[..., 0, 0, 0] = np.abs(w1[..., 0, 0, 0]) + 0.5
+    if masses:
+        m1 = mass(0.31, 0.12, -0.2, 0.6, 0.5, 0.05, sink_rate, 0.2, sink_model)
+        m2 = mass(-0.29, -0.11, 0.2, -0.6, 0.5, 0.05, sink_rate, 0.2, sink_model)
+    else:
+        m1 = m2 = NO_MASS
+    return dict(
+        shape=(ni, nj), extent=extent, w0=w0, w1=w1,
+        buffer=(0.8, m1[4] + m2[4], 100.0, max(abs(extent[1]), abs(extent[3])), 0.5, int(buffer_on)),
+        m1=m1, m2=m2, eos=(1.3, 100.0, eos), nu=nu, rk_param=rk_param, dt=dt, vmax=1e12,
+    )
+
+
+def dg_advance_args(c, w0, w1, w2):
+    return (*c["extent"], w0, w1, w2, *c["buffer"], *c["m1"], *c["m2"], *c["eos"], c["nu"], c["rk_param"], c["dt"],
+            c["vmax"])
+
+
+def dg_limit_args(c, w1, w2):
+    return (*c["extent"], c["m1"][0], c["m1"][1], c["m2"][0], c["m2"][1], w1, w2)
+
+
+def dg_wavespeed_args(c, w, out):
+    return (*c["extent"], *c["eos"], *c["m1"], *c["m2"], c["vmax"], w, out)
+
+
+def dg_branch_matrix():
+    combos = []
+    for eos, nu, buf, model, a in itertools.product((1, 2), (0.0, 0.01), (0, 1), (0, 1, 2, 3), (0.0, 0.5)):
+        combos.append(dict(eos=eos, nu=nu, buffer_on=bool(buf), sink_model=model, rk_param=a))
+    combos.append(dict(rk_param=0.75, rough=0.3))
+    combos.append(dict(rk_param=1.0 / 3.0, moments=0.3))
+    combos.append(dict(masses=False, eos=1, buffer_on=False, nu=0.0))
+    combos.append(dict(masses=False, eos=1, buffer_on=True, nu=0.01, rk_param=0.5))
+    combos.append(dict(sink_rate=-3.0, sink_model=1))
+    combos.append(dict(ni=5, nj=3))
+    combos.append(dict(ni=1, nj=1))
+    combos.append(dict(ni=37, nj=131))
+    return combos
+
+
+def dg_limit_matrix():
+    return [dict(), dict(moments=0.001), dict(moments=0.005), dict(moments=0.002, rough=0.002), dict(rough=0.3),
+            dict(rough=0.3, moments=0.5), dict(big_slopes=True), dict(big_slopes=True, rough=0.5),
+            dict(ni=1, nj=1, rough=0.5), dict(ni=37, nj=131, moments=0.003)]

@@ -138,3 +138,54 @@ def test_srhd_p2c_c2p_wavespeed_bitwise(macros, cold, adot):
         assert ORC.dll.sfo_srhd_2d_failures() == 0
     finally:
         ORC.dll.sfo_srhd_2d_set_macros(1.5, 1e6)
+
+
+# ---------------------------------------------------------------------------
+# cbdisodg_2d (oracle/sf_oracle_dg.c)
+# ---------------------------------------------------------------------------
+REF_DG = oracle.ref("cbdisodg_2d")
+need_dg = pytest.mark.skipif(REF_DG is None, reason="compiled reference (oracle/_ref) not available")
+
+
+@need_dg
+@pytest.mark.parametrize("kw", cases.dg_branch_matrix(), ids=SRHD_IDS)
+def test_dg_advance_bitwise(kw):
+    c = cases.dg_case(seed=17, **kw)
+    out_o = np.full_like(c["w1"], -7.0)
+    out_r = np.full_like(c["w1"], -7.0)
+    ORC.call("cbdisodg_2d_advance_rk", c["shape"], *cases.dg_advance_args(c, c["w0"], c["w1"], out_o))
+    REF_DG.call("cbdisodg_2d_advance_rk", c["shape"], *cases.dg_advance_args(c, c["w0"], c["w1"], out_r))
+    assert np.array_equal(out_o, out_r)
+    assert np.all(out_o[0] == -7.0) and np.all(out_o[:, -1] == -7.0)  # guards untouched
+    for m, n in ((1, 2), (2, 1), (2, 2)):
+        assert np.all(out_o[..., m, n] == -7.0)  # slots outside the scheme are not written
+    assert not np.any(out_o[1:-1, 1:-1, :, 0, 0] == -7.0)
+
+
+@need_dg
+@pytest.mark.parametrize("kw", cases.dg_limit_matrix(), ids=SRHD_IDS)
+def test_dg_slope_limit_bitwise(kw):
+    c = cases.dg_case(seed=23, **kw)
+    out_o = np.full_like(c["w1"], -7.0)
+    out_r = np.full_like(c["w1"], -7.0)
+    ORC.call("cbdisodg_2d_slope_limit", c["shape"], *cases.dg_limit_args(c, c["w1"], out_o))
+    REF_DG.call("cbdisodg_2d_slope_limit", c["shape"], *cases.dg_limit_args(c, c["w1"], out_r))
+    assert np.array_equal(out_o, out_r)
+    inner_in, inner_out = c["w1"][1:-1, 1:-1], out_o[1:-1, 1:-1]
+    assert np.array_equal(inner_out[..., 0, 0], inner_in[..., 0, 0])  # zone averages are never touched
+    limited = np.any(inner_out != inner_in, axis=(-1, -2))
+    if kw.get("moments", 1.0) <= 0.005:
+        assert limited.any() and not limited.all()  # both sides of the troubled-cell test
+    if kw.get("big_slopes"):
+        slopes = inner_out[limited][..., 1, 0]
+        assert np.all(slopes == np.trunc(slopes)) and np.any(slopes != 0.0)  # the reference's `int` return
+
+
+@need_dg
+@pytest.mark.parametrize("eos", [1, 2])
+def test_dg_wavespeed_bitwise(eos):
+    c = cases.dg_case(seed=3, eos=eos, ni=40, nj=23)
+    a, b = np.zeros(c["w1"].shape[:2]), np.zeros(c["w1"].shape[:2])
+    ORC.call("cbdisodg_2d_wavespeed", c["shape"], *cases.dg_wavespeed_args(c, c["w1"], a))
+    REF_DG.call("cbdisodg_2d_wavespeed", c["shape"], *cases.dg_wavespeed_args(c, c["w1"], b))
+    assert np.array_equal(a, b) and a[1:-1, 1:-1].min() > 0.0
