@@ -871,7 +871,7 @@ SFHIP_API int sfhip_cbdisodg_2d_stage(
     double wmass2,
     double wsoftening_length2,
     double *wavespeed_max, // :: $.numel() >= 1
-    double *dt_device) // :: $ is None or $.numel() >= 1
+    double *dt_device) // :: $.numel() >= 1
 ;
 
 #ifdef __cplusplus

@@ -1,0 +1,572 @@
+// sf_dg.hpp -- cbdisodg_2d on gfx950: third-order modal discontinuous-Galerkin update of the
+// isothermal binary-accretion problem (reference: /root/reference/sailfish/solvers/cbdisodg_2d.c;
+// line numbers below refer to it).
+//
+// Work decomposition.  One lane owns one zone (lanes run along j, the contiguous direction);
+// the zone's 18 live weights, the three 18-entry accumulators of the update (volume integral,
+// surface integral, sources) and one neighbour's weights stay in VGPRs.  The loops over the 9
+// volume nodes and the 12 face nodes are ROLLED: every per-node quantity that does not depend on
+// the zone -- basis values, Gauss weights, node offsets -- sits in a __constant__ table indexed by
+// the (wave-uniform) loop counter, so it arrives through scalar loads and is consumed as an SGPR
+// operand.  Unrolled, the kernel would be ~100 KB of code against a 64 KB instruction cache.
+//
+// Arithmetic.  The scheme's slope limiter takes discrete decisions (troubled-cell threshold,
+// "did minmod change the slope") on its inputs, so this file keeps the reference's operation
+// order with IEEE division and square root and no FMA contraction: except for pow()/exp() in
+// the point-mass source (device libm vs glibc, last-bit differences) every operation is the
+// reference's, and kernels that do not touch those two functions (limiter, wavespeed, and the
+// update wherever the masses are switched off) are bit-identical to it.  Three deliberate
+// savings change at most the sign of an exact zero: terms whose basis coefficient is zero for
+// EVERY node (x-derivatives of the m = 0 modes, y-derivatives of the n = 0 modes) are skipped,
+// and the face-normal "gradient" evaluation, which in the reference equals the face value
+// (basis_phi_1d returns the end-point value whatever `deriv` says, :383-390), reuses that value.
+#pragma once
+#include "sf_device.hpp"
+
+namespace sf {
+
+#pragma clang fp contract(off)
+
+constexpr int DG_NW = 27;                         // doubles per zone (3 fields x 3 x 3)
+constexpr int DG_K = 6;                           // used slots per field: m + n < 3
+constexpr int DG_SLOT[DG_K] = {0, 1, 2, 3, 4, 6}; // m * 3 + n for (0,0) (0,1) (0,2) (1,0) (1,1) (2,0)
+constexpr int DG_M[DG_K] = {0, 0, 0, 1, 1, 2};
+constexpr int DG_N[DG_K] = {0, 1, 2, 0, 1, 0};
+
+struct DgMass {
+    double x, y, vx, vy, mass, rsoft, sink_rate, sink_radius;
+    int sink_model;
+    int pad_;
+};
+
+struct DgParams {
+    int ni, nj;
+    double xl, yl, dx, dy, cell_volume;
+    int buffer_on, eos;
+    double buf_sd, buf_mass, buf_onset, buf_rate_prefix, buf_span; // prefix = driving_rate * omega_outer (:214-215)
+    DgMass m[2];
+    double cs2, mach2;
+    double nu, rk, dt, vmax;
+    int clamp_lo, clamp_hi, clamp_j, i_begin, i_end, want_ws;
+    double wx[2], wy[2], wm[2], wrs[2]; // point masses of the wavespeed epilogue
+    const double *dt_ptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Basis tables (:363-409), built at compile time with the reference's literals; a product of two
+// literals is rounded once, at compile time or at run time alike.
+// ---------------------------------------------------------------------------------------------
+constexpr double dg_basis(int at, int m, int deriv) // at: 0..2 Gauss node, 3 left end, 4 right end
+{
+    constexpr double node[3][3] = {
+        {+1.000000000000000, +1.00000000000000, +1.000000000000000},
+        {-1.341640786499873, +0.00000000000000, +1.341640786499873},
+        {+0.894427190999914, -1.11803398874990, +0.894427190999914},
+    };
+    constexpr double der[3][3] = {
+        {+0.000000000000000, +0.000000000000000, +0.000000000000000},
+        {+1.732050807568877, +1.732050807568877, +1.732050807568877},
+        {-5.196152422706629, +0.000000000000000, +5.196152422706629},
+    };
+    constexpr double left[3] = {+1.000000000000000, -1.732050807568877, +2.23606797749979};
+    constexpr double right[3] = {+1.000000000000000, +1.732050807568877, +2.23606797749979};
+    if (at == 3) return left[m];
+    if (at == 4) return right[m];
+    return deriv ? der[m][at] : node[m][at];
+}
+
+struct DgTables {
+    // volume nodes, index a * 3 + b
+    double vol_phi[9][DG_K]; // phi_volume
+    double vol_dpx[9][DG_K]; // phi_gradient_x
+    double vol_dpy[9][DG_K]; // phi_gradient_y
+    double vol_cx[9], vol_cy[9], vol_gw[9];
+    // face nodes, index quad * 4 + face (face: 0 xl, 1 xr, 2 yl, 3 yr); "own" is the zone's own
+    // trace on that face, "nb" the neighbour's
+    double face_own[12][DG_K]; // value, which is also the test function of the surface integral
+    double face_nb[12][DG_K];
+    double face_own_t[12][DG_K]; // tangential derivative
+    double face_nb_t[12][DG_K];
+    double face_cx[12], face_cy[12], face_gw[12];
+};
+
+constexpr DgTables dg_make_tables()
+{
+    constexpr double gw[3] = {0.555555555555556, 0.888888888888889, 0.555555555555556};  // :648
+    constexpr double gx[3] = {-0.774596669241483, 0.000000000000000, 0.774596669241483}; // :649
+    DgTables t = {};
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) {
+            const int nd = a * 3 + b;
+            for (int k = 0; k < DG_K; ++k) {
+                t.vol_phi[nd][k] = dg_basis(a, DG_M[k], 0) * dg_basis(b, DG_N[k], 0);
+                t.vol_dpx[nd][k] = dg_basis(a, DG_M[k], 1) * dg_basis(b, DG_N[k], 0);
+                t.vol_dpy[nd][k] = dg_basis(a, DG_M[k], 0) * dg_basis(b, DG_N[k], 1);
+            }
+            t.vol_cx[nd] = 0.5 * gx[a];
+            t.vol_cy[nd] = 0.5 * gx[b];
+            t.vol_gw[nd] = gw[a] * gw[b];
+        }
+    }
+    for (int q = 0; q < 3; ++q) {
+        for (int f = 0; f < 4; ++f) {
+            const int fn = q * 4 + f, dir = f >> 1, high = f & 1;
+            const int own_end = high ? 4 : 3, nb_end = high ? 3 : 4;
+            for (int k = 0; k < DG_K; ++k) {
+                const int m = DG_M[k], n = DG_N[k];
+                if (dir == 0) {
+                    t.face_own[fn][k] = dg_basis(own_end, m, 0) * dg_basis(q, n, 0);
+                    t.face_nb[fn][k] = dg_basis(nb_end, m, 0) * dg_basis(q, n, 0);
+                    t.face_own_t[fn][k] = dg_basis(own_end, m, 0) * dg_basis(q, n, 1);
+                    t.face_nb_t[fn][k] = dg_basis(nb_end, m, 0) * dg_basis(q, n, 1);
+                } else {
+                    t.face_own[fn][k] = dg_basis(q, m, 0) * dg_basis(own_end, n, 0);
+                    t.face_nb[fn][k] = dg_basis(q, m, 0) * dg_basis(nb_end, n, 0);
+                    t.face_own_t[fn][k] = dg_basis(q, m, 1) * dg_basis(own_end, n, 0);
+                    t.face_nb_t[fn][k] = dg_basis(q, m, 1) * dg_basis(nb_end, n, 0);
+                }
+            }
+            t.face_cx[fn] = dir == 0 ? (high ? 0.5 : -0.5) : 0.5 * gx[q];
+            t.face_cy[fn] = dir == 1 ? (high ? 0.5 : -0.5) : 0.5 * gx[q];
+            t.face_gw[fn] = gw[q];
+        }
+    }
+    return t;
+}
+
+__constant__ DgTables dg_tab = dg_make_tables();
+
+// ---------------------------------------------------------------------------------------------
+// Physics pieces, each the reference's expression tree
+// ---------------------------------------------------------------------------------------------
+
+// gravitational_potential + sound_speed_squared, :56-81, :171-188; masses given as 4 arrays
+__device__ __forceinline__ double dg_cs2(double cs2, double mach2, int eos, double x, double y,
+                                         const double (&mx)[2], const double (&my)[2], const double (&mm)[2],
+                                         const double (&mrs)[2])
+{
+    if (eos == 1) return cs2;
+    if (eos != 2) return 1.0;
+    double phi = 0.0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (mm[p] > 0.0) {
+            double ddx = x - mx[p];
+            double ddy = y - my[p];
+            double r2 = ddx * ddx + ddy * ddy;
+            phi -= mm[p] / sqrt(r2 + mrs[p] * mrs[p]);
+        }
+    }
+    return -phi / mach2;
+}
+
+// conserved_to_primitive, :227-241
+__device__ __forceinline__ void dg_c2p(const double (&u)[3], double (&p)[3], double vmax)
+{
+    p[0] = u[0];
+    p[1] = copysign(1.0, u[1]) * min2(fabs(u[1] / u[0]), vmax);
+    p[2] = copysign(1.0, u[2]) * min2(fabs(u[2] / u[0]), vmax);
+}
+
+// primitive_to_flux, :255-269, with the direction as two 0/1 factors
+__device__ __forceinline__ void dg_flux(const double (&p)[3], const double (&u)[3], double cs2, double vn, double e0,
+                                        double e1, double (&f)[3])
+{
+    double pressure = p[0] * cs2;
+    f[0] = vn * u[0];
+    f[1] = vn * u[1] + pressure * e0;
+    f[2] = vn * u[2] + pressure * e1;
+}
+
+// The four velocity gradients and three stresses of add_viscous_flux, :326-349 (mu included)
+__device__ __forceinline__ void dg_stress(const double (&u)[3], const double (&ux)[3], const double (&uy)[3], double nu,
+                                          double dx, double dy, double &txx, double &txy, double &tyy)
+{
+    double dvxdx = 2.0 * (ux[1] / u[0] - u[1] * ux[0] / u[0] / u[0]) / dx;
+    double dvydx = 2.0 * (ux[2] / u[0] - u[2] * ux[0] / u[0] / u[0]) / dx;
+    double dvxdy = 2.0 * (uy[1] / u[0] - u[1] * uy[0] / u[0] / u[0]) / dy;
+    double dvydy = 2.0 * (uy[2] / u[0] - u[2] * uy[0] / u[0] / u[0]) / dy;
+    double mu = u[0] * nu;
+    double sxx = 4.0 / 3.0 * dvxdx - 2.0 / 3.0 * dvydy;
+    double syy = 4.0 / 3.0 * dvydy - 2.0 / 3.0 * dvxdx;
+    double sxy = dvxdy + dvydx;
+    txx = mu * sxx;
+    txy = mu * sxy;
+    tyy = mu * syy;
+}
+
+// point_mass_source_term, :83-152.  pow(x, -1.5) and exp() are the two operations of this file
+// that are not the reference's bit for bit.
+__device__ __forceinline__ void dg_mass_source(const DgMass &ms, double x, double y, double dt, const double (&prim)[3],
+                                               double (&du)[3])
+{
+    double sigma = prim[0];
+    double ddx = x - ms.x;
+    double ddy = y - ms.y;
+    double r2 = ddx * ddx + ddy * ddy;
+    double dr = sqrt(r2);
+    double rs2 = r2 + ms.rsoft * ms.rsoft;
+    double fnum = sigma * ms.mass * (1.0 / (rs2 * sqrt(rs2)));
+    double fx = -fnum * ddx;
+    double fy = -fnum * ddy;
+    double rate = 0.0;
+    if (dr < 4.0 * ms.sink_radius) {
+        double s = dr / ms.sink_radius;
+        double s2 = s * s;
+        rate = ms.sink_rate * exp(-(s2 * s2));
+    }
+    double mdot = sigma * rate * -1.0;
+    du[0] += 0.0;
+    du[1] += fx * dt;
+    du[2] += fy * dt;
+    switch (ms.sink_model) {
+    case 1:
+        du[0] += dt * mdot;
+        du[1] += dt * mdot * prim[1];
+        du[2] += dt * mdot * prim[2];
+        break;
+    case 2: {
+        double rhx = ddx / (dr + 1e-12);
+        double rhy = ddy / (dr + 1e-12);
+        double dv = (prim[1] - ms.vx) * rhx + (prim[2] - ms.vy) * rhy;
+        double vxs = dv * rhx + ms.vx;
+        double vys = dv * rhy + ms.vy;
+        du[0] += dt * mdot;
+        du[1] += dt * mdot * vxs;
+        du[2] += dt * mdot * vys;
+        break;
+    }
+    case 3:
+        du[0] += dt * mdot;
+        du[1] += 0.0;
+        du[2] += 0.0;
+        break;
+    default:
+        du[0] += 0.0;
+        du[1] += 0.0;
+        du[2] += 0.0;
+        break;
+    }
+}
+
+// buffer_source_term, :190-223
+__device__ __forceinline__ void dg_buffer_source(const DgParams &P, double x, double y, double dt, const double (&u)[3],
+                                                 double (&du)[3])
+{
+    if (!P.buffer_on) return;
+    double rc = sqrt(x * x + y * y);
+    if (rc > P.buf_onset) {
+        double vk = sqrt(P.buf_mass / rc);
+        double u0[3] = {P.buf_sd, P.buf_sd * (-y / rc) * vk, P.buf_sd * (+x / rc) * vk};
+        double rate = P.buf_rate_prefix * (rc - P.buf_onset) / P.buf_span;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            du[q] -= (u[q] - u0[q]) * rate * dt;
+    }
+}
+
+// sum_k w[q][k] * c[k] from 0.0, in slot order (reconstruct_2d / reconstruct_1d, :411-453);
+// slots whose bit is clear in MASK have a zero coefficient at every node and are skipped
+template <int MASK>
+__device__ __forceinline__ void dg_eval(const double (&w)[3][DG_K], const double *c, double (&out)[3])
+{
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < DG_K; ++k)
+            if (MASK & (1 << k)) s += w[q][k] * c[k];
+        out[q] = s;
+    }
+}
+
+__device__ __forceinline__ void dg_load(const double *zone, double (&w)[3][DG_K])
+{
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k = 0; k < DG_K; ++k)
+            w[q][k] = zone[q * 9 + DG_SLOT[k]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// cbdisodg_2d_advance_rk, :607-983 (+ index clamps, device dt and wavespeed epilogue; sfhip.h)
+// grid: (ceil(nj / 64), i_end - i_begin), block 64
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double *__restrict__ weights0,
+                                                        const double *__restrict__ weights1,
+                                                        double *__restrict__ weights2, double *wavespeed_max)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = P.i_begin + blockIdx.y;
+    const bool active = j < P.nj;
+    double speed = 0.0;
+    if (active) {
+        const long sj = DG_NW, si = (long)DG_NW * (P.nj + 2);
+        const long at = (i + 1) * si + (j + 1) * sj;
+        const double dt = P.dt_ptr ? *P.dt_ptr : P.dt;
+        const double dx = P.dx, dy = P.dy;
+        const double xc = P.xl + (i + 0.5) * dx;
+        const double yc = P.yl + (j + 0.5) * dy;
+        const double mx[2] = {P.m[0].x, P.m[1].x}, my[2] = {P.m[0].y, P.m[1].y};
+        const double mm[2] = {P.m[0].mass, P.m[1].mass}, mrs[2] = {P.m[0].rsoft, P.m[1].rsoft};
+        const bool viscous = P.nu > 0.0;
+
+        double cc[3][DG_K];
+        dg_load(weights1 + at, cc);
+
+        // neighbour offsets, by face; an outflow edge's guard zone is a copy of the edge zone itself
+        long nb_off[4] = {-si, +si, -sj, +sj};
+        if (P.clamp_lo && i == 0) nb_off[0] = 0;
+        if (P.clamp_hi && i == P.ni - 1) nb_off[1] = 0;
+        if (P.clamp_j && j == 0) nb_off[2] = 0;
+        if (P.clamp_j && j == P.nj - 1) nb_off[3] = 0;
+
+        double vol[3][DG_K], srf[3][DG_K], src[3][DG_K]; // equation_19, equation_20, source_weights
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int k = 0; k < DG_K; ++k)
+                vol[q][k] = srf[q][k] = src[q][k] = 0.0;
+
+        // ---- surface integral, :848-961: per Gauss node the faces xl, xr, yl, yr ----------
+#pragma unroll 1
+        for (int fn = 0; fn < 12; ++fn) {
+            const int face = fn & 3;
+            const bool high = face & 1, ydir = face >> 1;
+            const double x = xc + dg_tab.face_cx[fn] * dx;
+            const double y = yc + dg_tab.face_cy[fn] * dy;
+            const double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, x, y, mx, my, mm, mrs);
+            double nb[3][DG_K];
+            dg_load(weights1 + at + (face == 0 ? nb_off[0] : face == 1 ? nb_off[1] : face == 2 ? nb_off[2] : nb_off[3]), nb);
+            double uo[3], un[3]; // own and neighbour traces
+            dg_eval<63>(cc, dg_tab.face_own[fn], uo);
+            dg_eval<63>(nb, dg_tab.face_nb[fn], un);
+            double um[3], up[3]; // low-side and high-side states
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                um[q] = high ? uo[q] : un[q];
+                up[q] = high ? un[q] : uo[q];
+            }
+            // riemann_hlle, :295-324
+            double pl[3], pr[3], fl[3], fr[3], fhat[3];
+            dg_c2p(um, pl, P.vmax);
+            dg_c2p(up, pr, P.vmax);
+            const double e0 = ydir ? 0.0 : 1.0, e1 = ydir ? 1.0 : 0.0;
+            const double vl = ydir ? pl[2] : pl[1], vr = ydir ? pr[2] : pr[1];
+            dg_flux(pl, um, cs2, vl, e0, e1, fl);
+            dg_flux(pr, up, cs2, vr, e0, e1, fr);
+            const double cs = sqrt(cs2);
+            const double am = min2(0.0, min2(vl - cs, vr - cs));
+            const double ap = max2(0.0, max2(vl + cs, vr + cs));
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                fhat[q] = (fl[q] * ap - fr[q] * am - (um[q] - up[q]) * ap * am) / (ap - am);
+            if (viscous) {
+                // high side first, then low side (:860-869); the face-normal "gradient" IS the trace
+                double to[3], tn[3];
+                dg_eval<63>(cc, dg_tab.face_own_t[fn], to);
+                dg_eval<63>(nb, dg_tab.face_nb_t[fn], tn);
+                double oxx, oxy, oyy, nxx, nxy, nyy;
+                double gxo[3], gyo[3], gxn[3], gyn[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    gxo[q] = ydir ? to[q] : uo[q];
+                    gyo[q] = ydir ? uo[q] : to[q];
+                    gxn[q] = ydir ? tn[q] : un[q];
+                    gyn[q] = ydir ? un[q] : tn[q];
+                }
+                dg_stress(uo, gxo, gyo, P.nu, dx, dy, oxx, oxy, oyy);
+                dg_stress(un, gxn, gyn, P.nu, dx, dy, nxx, nxy, nyy);
+                const double o1 = ydir ? oxy : oxx, o2 = ydir ? oyy : oxy;
+                const double n1 = ydir ? nxy : nxx, n2 = ydir ? nyy : nxy;
+                fhat[1] -= high ? n1 : o1;
+                fhat[2] -= high ? n2 : o2;
+                fhat[1] -= high ? o1 : n1;
+                fhat[2] -= high ? o2 : n2;
+            }
+            const double len = ydir ? dx : dy;
+            const double gw = dg_tab.face_gw[fn];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int k = 0; k < DG_K; ++k) {
+                    double term = len * fhat[q] * dg_tab.face_own[fn][k] * gw;
+                    srf[q][k] += high ? term : -term;
+                }
+            }
+        }
+
+        // ---- volume integral and sources, :776-844 ---------------------------------------
+#pragma unroll 1
+        for (int nd = 0; nd < 9; ++nd) {
+            const double x = xc + dg_tab.vol_cx[nd] * dx;
+            const double y = yc + dg_tab.vol_cy[nd] * dy;
+            const double gw = dg_tab.vol_gw[nd];
+            const double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, x, y, mx, my, mm, mrs);
+            double u[3], p[3], fx[3], fy[3];
+            dg_eval<63>(cc, dg_tab.vol_phi[nd], u);
+            dg_c2p(u, p, P.vmax);
+            dg_flux(p, u, cs2, p[1], 1.0, 0.0, fx);
+            dg_flux(p, u, cs2, p[2], 0.0, 1.0, fy);
+            if (viscous) {
+                double ux[3], uy[3], txx, txy, tyy;
+                dg_eval<0x38>(cc, dg_tab.vol_dpx[nd], ux); // m >= 1: slots 3, 4, 5
+                dg_eval<0x16>(cc, dg_tab.vol_dpy[nd], uy); // n >= 1: slots 1, 2, 4
+                dg_stress(u, ux, uy, P.nu, dx, dy, txx, txy, tyy);
+                fx[1] -= txx;
+                fx[2] -= txy;
+                fy[1] -= txy;
+                fy[2] -= tyy;
+            }
+#pragma unroll
+            for (int k = 1; k < DG_K; ++k) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (0x38 & (1 << k)) vol[q][k] += dx * fx[q] * dg_tab.vol_dpx[nd][k] * gw;
+                    if (0x16 & (1 << k)) vol[q][k] += dy * fy[q] * dg_tab.vol_dpy[nd][k] * gw;
+                }
+            }
+            double du[3] = {0.0, 0.0, 0.0};
+            dg_buffer_source(P, x, y, dt, u, du);
+            dg_mass_source(P.m[0], x, y, dt, p, du);
+            dg_mass_source(P.m[1], x, y, dt, p, du);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int k = 0; k < DG_K; ++k)
+                    src[q][k] += 0.25 * du[q] * dg_tab.vol_phi[nd][k] * gw;
+        }
+
+        // ---- :963-981 -------------------------------------------------------------------------
+        const double *w0 = weights0 + at;
+        double *w2 = weights2 + at;
+        double avg[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int k = 0; k < DG_K; ++k) {
+                const int s = q * 9 + DG_SLOT[k];
+                double w = cc[q][k] + (vol[q][k] - srf[q][k]) * 0.5 * dt / P.cell_volume + src[q][k];
+                w = (1.0 - P.rk) * w + P.rk * w0[s];
+                w2[s] = w;
+                if (k == 0) avg[q] = w;
+            }
+        }
+
+        if (P.want_ws) { // cbdisodg_2d_wavespeed (:1152-1175) of the zone just written
+            double pa[3];
+            dg_c2p(avg, pa, P.vmax);
+            double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, xc, yc, P.wx, P.wy, P.wm, P.wrs);
+            speed = max_speed(pa[1], pa[2], cs2);
+        }
+    }
+    if (P.want_ws) {
+        speed = wave_max_nonneg(speed);
+        if (threadIdx.x == 0) atomic_max_nonneg(wavespeed_max, speed);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cbdisodg_2d_slope_limit, :498-605.  grid: (ceil(nj / 64), i_end - i_begin), block 64
+// ---------------------------------------------------------------------------------------------
+
+// minmod_simple, :455-493, including the truncation of its `int` return type; out-of-range and
+// NaN picks give INT_MIN as the reference's x86 conversion does
+__device__ __forceinline__ double dg_minmod_truncated(double w1, double w0l, double w0, double w0r)
+{
+    const double s3 = 1.7320508075688772; // sqrt(3.0), correctly rounded
+    double a = w1;
+    double b = (w0 - w0l) * 1.0 / s3;
+    double c = (w0r - w0) * 1.0 / s3;
+    double pick = 0.0;
+    if (a <= 0.0 && b <= 0.0 && c <= 0.0) {
+        if (a >= b && a >= c) pick = a;
+        else if (b >= c && b >= a) pick = b;
+        else pick = c;
+    } else if (a >= 0.0 && b >= 0.0 && c >= 0.0) {
+        if (a <= b && a <= c) pick = a;
+        else if (b <= c && b <= a) pick = b;
+        else pick = c;
+    }
+    if (!(fabs(pick) < 2147483648.0)) return -2147483648.0;
+    return (double)(int)pick;
+}
+
+__global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const double *__restrict__ weights1,
+                                                      double *__restrict__ weights2, int clamp_lo, int clamp_hi,
+                                                      int clamp_j, int i_begin)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = i_begin + blockIdx.y;
+    if (j >= nj) return;
+    const long sj = DG_NW, si = (long)DG_NW * (nj + 2);
+    const double *cc = weights1 + (i + 1) * si + (j + 1) * sj;
+    const double *li = (clamp_lo && i == 0) ? cc : cc - si;
+    const double *ri = (clamp_hi && i == ni - 1) ? cc : cc + si;
+    const double *lj = (clamp_j && j == 0) ? cc : cc - sj;
+    const double *rj = (clamp_j && j == nj - 1) ? cc : cc + sj;
+    double *out = weights2 + (i + 1) * si + (j + 1) * sj;
+
+    double w[DG_NW];
+#pragma unroll
+    for (int k = 0; k < DG_NW; ++k)
+        w[k] = cc[k];
+
+    const double s3 = 1.7320508075688772, s5 = 2.23606797749979; // sqrt(3.0), sqrt(5.0) correctly rounded
+    const double c00 = w[0];
+    const double big = max2(max2(fabs(c00), fabs(li[0])), max2(fabs(ri[0]), max2(fabs(lj[0]), fabs(rj[0]))));
+    const double a = 4.0 * li[0] + 8.0 * s3 * li[3] + 24.0 * s5 * li[6];
+    const double b = 4.0 * ri[0] - 8.0 * s3 * ri[3] + 24.0 * s5 * ri[6];
+    const double c = 4.0 * lj[0] + 8.0 * s3 * lj[1] + 24.0 * s5 * lj[2];
+    const double d = 4.0 * rj[0] - 8.0 * s3 * rj[1] + 24.0 * s5 * rj[2];
+    const double tci = (fabs(c00 - a / 4.0) + fabs(c00 - b / 4.0) + fabs(c00 - c / 4.0) + fabs(c00 - d / 4.0)) / big;
+    if (tci > 0.1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double wx = dg_minmod_truncated(w[q * 9 + 3], li[q * 9], w[q * 9], ri[q * 9]);
+            const double wy = dg_minmod_truncated(w[q * 9 + 1], lj[q * 9], w[q * 9], rj[q * 9]);
+            if (wx != w[q * 9 + 3] || wy != w[q * 9 + 1]) {
+#pragma unroll
+                for (int k = 1; k < 9; ++k)
+                    w[q * 9 + k] = 0.0;
+                w[q * 9 + 3] = wx;
+                w[q * 9 + 1] = wy;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DG_NW; ++k)
+        out[k] = w[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// cbdisodg_2d_wavespeed, :1108-1176, as a per-zone array (reference form) and/or folded into a
+// device scalar.  grid: (ceil(nj / 64), ni), block 64
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dg_wavespeed_kernel(DgParams P, const double *__restrict__ weights,
+                                                          double *__restrict__ wavespeed, double *wavespeed_max)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y;
+    double speed = 0.0;
+    if (j < P.nj) {
+        const double *cc = weights + ((long)(i + 1) * (P.nj + 2) + (j + 1)) * DG_NW;
+        const double x = P.xl + (i + 0.5) * P.dx;
+        const double y = P.yl + (j + 0.5) * P.dy;
+        const double u[3] = {cc[0], cc[9], cc[18]};
+        double p[3];
+        dg_c2p(u, p, P.vmax);
+        const double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, x, y, P.wx, P.wy, P.wm, P.wrs);
+        speed = max_speed(p[1], p[2], cs2);
+        if (wavespeed) wavespeed[(long)(i + 1) * (P.nj + 2) + (j + 1)] = speed;
+    }
+    if (wavespeed_max) {
+        speed = wave_max_nonneg(speed);
+        if (threadIdx.x == 0) atomic_max_nonneg(wavespeed_max, speed);
+    }
+}
+
+#pragma clang fp contract(fast)
+
+} // namespace sf

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "sf_dg.hpp"
 #include "sf_gam.hpp"
 #include "sf_iso.hpp"
 #include "sf_reduce.hpp"
@@ -859,6 +860,203 @@ int sfhip_srhd_2d_failures(int n, double *out)
     e = hipMemcpy(out, &value, sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// cbdisodg_2d -- reference-named entry points and their clamped / fused forms
+// ---------------------------------------------------------------------------
+namespace {
+
+sf::DgMass dg_mass(double x, double y, double vx, double vy, double mass, double rsoft, double rate, double rsink, int model)
+{
+    sf::DgMass m;
+    m.x = x; m.y = y; m.vx = vx; m.vy = vy; m.mass = mass; m.rsoft = rsoft;
+    m.sink_rate = rate; m.sink_radius = rsink; m.sink_model = model; m.pad_ = 0;
+    return m;
+}
+
+int dg_mesh(sf::DgParams &P, const char *who, int ni, int nj, double xl, double xr, double yl, double yr)
+{
+    if (ni < 1 || nj < 1) return fail(-1, who);
+    memset(&P, 0, sizeof(P));
+    P.ni = ni; P.nj = nj;
+    P.xl = xl; P.yl = yl;
+    P.dx = (xr - xl) / ni; // cbdisodg_2d.c:650-652
+    P.dy = (yr - yl) / nj;
+    P.cell_volume = P.dx * P.dy;
+    return 0;
+}
+
+int dg_stage_impl(
+    const char *who, int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *weights0, double *weights1, double *weights2,
+    double buffer_surface_density, double buffer_central_mass, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    const sf::DgMass &m1, const sf::DgMass &m2, double soundspeed2, double mach_squared, int eos_type,
+    double nu, double rk_param, double dt, double velocity_ceiling,
+    int clamp_lower_i, int clamp_upper_i, int clamp_j, int i_begin, int i_end, int want_wavespeed,
+    const double *wmass8, double *wavespeed_max, double *dt_device)
+{
+    sf::DgParams P;
+    int rc = dg_mesh(P, who, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr);
+    if (rc) return rc;
+    if (!weights0 || !weights1 || !weights2) return fail(-1, who);
+    if (weights2 == weights1 || weights2 == weights0) return fail(-1, "cbdisodg_2d: weights2 must not alias an input");
+    if (i_begin < 0 || i_end > ni || i_begin > i_end) return fail(-1, "cbdisodg_2d: bad row range");
+    if (want_wavespeed < 0 || want_wavespeed > 2 || (want_wavespeed && !wavespeed_max)) return fail(-1, who);
+    P.buffer_on = buffer_is_enabled;
+    P.eos = eos_type;
+    P.buf_sd = buffer_surface_density;
+    P.buf_mass = buffer_central_mass;
+    P.buf_onset = buffer_outer_radius - buffer_onset_width;                                 // cbdisodg_2d.c:206
+    P.buf_rate_prefix = buffer_driving_rate * sqrt(buffer_central_mass * pow(P.buf_onset, -3.0)); // :214-215, host libm
+    P.buf_span = buffer_outer_radius - P.buf_onset;
+    P.m[0] = m1; P.m[1] = m2;
+    P.cs2 = soundspeed2; P.mach2 = mach_squared;
+    P.nu = nu; P.rk = rk_param; P.dt = dt; P.vmax = velocity_ceiling;
+    P.clamp_lo = clamp_lower_i; P.clamp_hi = clamp_upper_i; P.clamp_j = clamp_j;
+    P.i_begin = i_begin; P.i_end = i_end; P.want_ws = want_wavespeed ? 1 : 0;
+    if (wmass8) {
+        for (int p = 0; p < 2; ++p) {
+            P.wx[p] = wmass8[4 * p + 0]; P.wy[p] = wmass8[4 * p + 1];
+            P.wm[p] = wmass8[4 * p + 2]; P.wrs[p] = wmass8[4 * p + 3];
+        }
+    }
+    P.dt_ptr = dt_device;
+    if (want_wavespeed == 2) {
+        hipError_t e = hipMemsetAsync(wavespeed_max, 0, sizeof(double), t_stream);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    if (i_end == i_begin) return 0;
+    dim3 block(64), grid((nj + 63) / 64, i_end - i_begin);
+    hipLaunchKernelGGL(sf::dg_advance_kernel, grid, block, 0, t_stream, P, weights0, weights1, weights2, wavespeed_max);
+    return check_launch(who);
+}
+
+int dg_wavespeed_impl(const char *who, int ni, int nj, double xl, double xr, double yl, double yr, double soundspeed2,
+                      double mach_squared, int eos_type, const double *wmass8, double velocity_ceiling,
+                      double *weights, double *wavespeed, double *wavespeed_max)
+{
+    sf::DgParams P;
+    int rc = dg_mesh(P, who, ni, nj, xl, xr, yl, yr);
+    if (rc) return rc;
+    if (!weights || (!wavespeed && !wavespeed_max)) return fail(-1, who);
+    P.cs2 = soundspeed2; P.mach2 = mach_squared; P.eos = eos_type; P.vmax = velocity_ceiling;
+    for (int p = 0; p < 2; ++p) {
+        P.wx[p] = wmass8[4 * p + 0]; P.wy[p] = wmass8[4 * p + 1];
+        P.wm[p] = wmass8[4 * p + 2]; P.wrs[p] = wmass8[4 * p + 3];
+    }
+    if (wavespeed_max) {
+        hipError_t e = hipMemsetAsync(wavespeed_max, 0, sizeof(double), t_stream);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    dim3 block(64), grid((nj + 63) / 64, ni);
+    hipLaunchKernelGGL(sf::dg_wavespeed_kernel, grid, block, 0, t_stream, P, weights, wavespeed, wavespeed_max);
+    return check_launch(who);
+}
+
+int dg_limit_impl(const char *who, int ni, int nj, double *weights1, double *weights2, int clamp_lower_i,
+                  int clamp_upper_i, int clamp_j, int i_begin, int i_end)
+{
+    if (ni < 1 || nj < 1 || !weights1 || !weights2 || weights1 == weights2) return fail(-1, who);
+    if (i_begin < 0 || i_end > ni || i_begin > i_end) return fail(-1, "cbdisodg_2d: bad row range");
+    if (i_end == i_begin) return 0;
+    dim3 block(64), grid((nj + 63) / 64, i_end - i_begin);
+    hipLaunchKernelGGL(sf::dg_limit_kernel, grid, block, 0, t_stream, ni, nj, weights1, weights2, clamp_lower_i,
+                       clamp_upper_i, clamp_j, i_begin);
+    return check_launch(who);
+}
+
+} // namespace
+
+extern "C" {
+
+int cbdisodg_2d_slope_limit(int ni, int nj, double, double, double, double, double, double, double, double,
+                            double *weights1, double *weights2)
+{
+    return dg_limit_impl("cbdisodg_2d_slope_limit: bad arguments", ni, nj, weights1, weights2, 0, 0, 0, 0, ni);
+}
+
+int sfhip_cbdisodg_2d_limit(int ni, int nj, double *weights1, double *weights2, int clamp_lower_i, int clamp_upper_i,
+                            int clamp_j, int i_begin, int i_end)
+{
+    return dg_limit_impl("sfhip_cbdisodg_2d_limit: bad arguments", ni, nj, weights1, weights2, clamp_lower_i,
+                         clamp_upper_i, clamp_j, i_begin, i_end);
+}
+
+int cbdisodg_2d_advance_rk(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *weights0, double *weights1, double *weights2,
+    double buffer_surface_density, double buffer_central_mass, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double soundspeed2, double mach_squared, int eos_type, double nu, double rk_param, double dt,
+    double velocity_ceiling)
+{
+    return dg_stage_impl("cbdisodg_2d_advance_rk: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+        weights0, weights1, weights2, buffer_surface_density, buffer_central_mass, buffer_driving_rate,
+        buffer_outer_radius, buffer_onset_width, buffer_is_enabled,
+        dg_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+        dg_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+        soundspeed2, mach_squared, eos_type, nu, rk_param, dt, velocity_ceiling,
+        0, 0, 0, 0, ni, 0, nullptr, nullptr, nullptr);
+}
+
+int sfhip_cbdisodg_2d_stage(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double *weights0, double *weights1, double *weights2,
+    double buffer_surface_density, double buffer_central_mass, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double soundspeed2, double mach_squared, int eos_type, double nu, double rk_param, double dt,
+    double velocity_ceiling,
+    int clamp_lower_i, int clamp_upper_i, int clamp_j, int i_begin, int i_end, int want_wavespeed,
+    double wx1, double wy1, double wmass1, double wsoftening_length1,
+    double wx2, double wy2, double wmass2, double wsoftening_length2,
+    double *wavespeed_max, double *dt_device)
+{
+    const double w[8] = {wx1, wy1, wmass1, wsoftening_length1, wx2, wy2, wmass2, wsoftening_length2};
+    return dg_stage_impl("sfhip_cbdisodg_2d_stage: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+        weights0, weights1, weights2, buffer_surface_density, buffer_central_mass, buffer_driving_rate,
+        buffer_outer_radius, buffer_onset_width, buffer_is_enabled,
+        dg_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+        dg_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+        soundspeed2, mach_squared, eos_type, nu, rk_param, dt, velocity_ceiling,
+        clamp_lower_i, clamp_upper_i, clamp_j, i_begin, i_end, want_wavespeed, w, wavespeed_max, dt_device);
+}
+
+int cbdisodg_2d_wavespeed(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double soundspeed2, double mach_squared, int eos_type,
+    double x1, double y1, double, double, double mass1, double softening_length1, double, double, int,
+    double x2, double y2, double, double, double mass2, double softening_length2, double, double, int,
+    double velocity_ceiling, double *weights, double *wavespeed)
+{
+    const double w[8] = {x1, y1, mass1, softening_length1, x2, y2, mass2, softening_length2};
+    return dg_wavespeed_impl("cbdisodg_2d_wavespeed: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
+                             soundspeed2, mach_squared, eos_type, w, velocity_ceiling, weights, wavespeed, nullptr);
+}
+
+int sfhip_cbdisodg_2d_max_wavespeed(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double soundspeed2, double mach_squared, int eos_type,
+    double x1, double y1, double mass1, double softening_length1,
+    double x2, double y2, double mass2, double softening_length2,
+    double velocity_ceiling, double *weights, double *wavespeed_max)
+{
+    const double w[8] = {x1, y1, mass1, softening_length1, x2, y2, mass2, softening_length2};
+    if (!wavespeed_max) return fail(-1, "sfhip_cbdisodg_2d_max_wavespeed: null wavespeed_max");
+    return dg_wavespeed_impl("sfhip_cbdisodg_2d_max_wavespeed: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl,
+                             patch_yr, soundspeed2, mach_squared, eos_type, w, velocity_ceiling, weights, nullptr,
+                             wavespeed_max);
 }
 
 } // extern "C"
