@@ -1,5 +1,5 @@
 """
-The two setups that feed the hot path.
+The setups that feed the hot path.
 
 ``CircumbinaryDisk`` is the benchmark problem (reference:
 ``sailfish/setups/circumbinary_disk.py:17-215``): it defines the synthetic input
@@ -52,6 +52,13 @@ class Setup:
         for i in range(i0, i1):
             for j in range(mesh.nj):
                 self.primitive(t, mesh.cell_coordinates(i, j), out[i - i0, j])
+        return out
+
+    def primitive_points(self, t, x, y, num_fields):
+        """Primitive data at arbitrary points (arrays x, y of one shape); fallback: per-point loop."""
+        out = np.zeros(x.shape + (num_fields,))
+        for idx in np.ndindex(*x.shape):
+            self.primitive(t, (float(x[idx]), float(y[idx])), out[idx])
         return out
 
 
@@ -130,12 +137,20 @@ class CircumbinaryDisk(Setup):
         j = np.arange(mesh.nj, dtype=np.float64)[None, :]
         x = mesh.x0 + (i + 0.5) * mesh.dx
         y = mesh.y0 + (j + 0.5) * mesh.dy
+        return self._primitive_vectorised(x, y, (i1 - i0, mesh.nj))
+
+    def primitive_points(self, t, x, y, num_fields=None):
+        if self.is_gamma_law and x.size <= (1 << 18):
+            return Setup.primitive_points(self, t, x, y, 4)
+        return self._primitive_vectorised(x, y, x.shape)
+
+    def _primitive_vectorised(self, x, y, shape):
         r2 = x * x + y * y
         r = np.sqrt(r2)
         rs = np.sqrt(r2 + self.softening_length * self.softening_length)
         rc = np.maximum(r, 1e-12)
         vk = np.sqrt(1.0 / rs)
-        out = np.zeros([i1 - i0, mesh.nj, self.num_fields])
+        out = np.zeros([*shape, self.num_fields])
         out[..., 1] = vk * (-y / rc)
         out[..., 2] = vk * (+x / rc)
         if self.is_isothermal:
@@ -213,9 +228,143 @@ class CircumbinaryDisk(Setup):
         return tuple(PointMass(**common, **body._asdict()) for body in self.orbital_elements.orbital_state(time))
 
 
+class KitpCodeComparison(Setup):
+    """
+    The code-comparison disk of the reference (``sailfish/setups/circumbinary_disk.py:218-375``): a
+    locally isothermal disk with a depleted cavity inside r = 2.5, sub-Keplerian rotation blended into
+    the binary's frequency near the centre, and a small radial kick.  It is the circumbinary setup that
+    can select the discontinuous-Galerkin solver (``use_dg``).
+    """
+
+    mach_number = 10.0
+    eccentricity = 0.0
+    mass_ratio = 1.0
+    sink_radius = 0.05
+    softening_length = 0.05
+    nu = 0.001
+    single_point_mass = False
+    sink_model = "acceleration_free"
+    domain_radius = 8.0
+    sink_rate = 10.0
+    buffer_is_enabled = True
+    use_dg = False
+    disk_kick = 1e-4
+    which_diagnostics = "kitp"
+
+    reference_time_scale = 2.0 * pi
+    default_end_time = 1.0
+    default_resolution = 200
+
+    def validate(self):
+        if self.which_diagnostics not in ("kitp", "forces"):
+            raise SetupError("Unknown option for diagnostics.")
+
+    def primitive(self, t, coords, primitive):
+        """Per-point initial data, circumbinary_disk.py:242-263 (Python floats, as there)."""
+        x, y = coords
+        r = sqrt(x * x + y * y)
+        sigma = 1.0 * (1e-5 + (1 - 1e-5) * exp(-((2.5 / r) ** 12)))
+        omega_b = (1.0 / 1.0**3) ** 0.5
+        omega_0 = (1.0 / r**3 * (1.0 - 1.0 / self.mach_number**2)) ** 0.5
+        omega = (omega_0**-4.0 + omega_b**-4.0) ** (-1 / 4.0)
+        kick = self.disk_kick * y * exp(-((r / 3.5) ** 6))
+        primitive[0] = sigma
+        primitive[1] = omega * -y + kick * x / r
+        primitive[2] = omega * +x + kick * y / r
+
+    def primitive_array(self, t, mesh, i0=0, i1=None, num_fields=None):
+        i1 = mesh.ni if i1 is None else i1
+        if (i1 - i0) * mesh.nj <= (1 << 18):
+            return Setup.primitive_array(self, t, mesh, i0, i1, 3)
+        i = np.arange(i0, i1, dtype=np.float64)[:, None]
+        j = np.arange(mesh.nj, dtype=np.float64)[None, :]
+        x = np.broadcast_to(mesh.x0 + (i + 0.5) * mesh.dx, (i1 - i0, mesh.nj))
+        y = np.broadcast_to(mesh.y0 + (j + 0.5) * mesh.dy, (i1 - i0, mesh.nj))
+        return self._primitive_vectorised(x, y)
+
+    def primitive_points(self, t, x, y, num_fields=None):
+        """Small inputs take the exact per-point loop; large ones numpy (pow/exp: last-place differences)."""
+        if x.size <= (1 << 18):
+            return Setup.primitive_points(self, t, x, y, 3)
+        return self._primitive_vectorised(x, y)
+
+    def _primitive_vectorised(self, x, y):
+        r = np.sqrt(x * x + y * y)
+        sigma = 1.0 * (1e-5 + (1 - 1e-5) * np.exp(-((2.5 / r) ** 12)))
+        omega_0 = (1.0 / r**3 * (1.0 - 1.0 / self.mach_number**2)) ** 0.5
+        omega = (omega_0**-4.0 + 1.0) ** (-1 / 4.0)
+        kick = self.disk_kick * y * np.exp(-((r / 3.5) ** 6))
+        out = np.empty(x.shape + (3,))
+        out[..., 0] = sigma
+        out[..., 1] = omega * -y + kick * x / r
+        out[..., 2] = omega * +x + kick * y / r
+        return out
+
+    def mesh(self, resolution):
+        return PlanarCartesian2DMesh.centered_square(self.domain_radius, resolution)
+
+    @property
+    def diagnostics(self):
+        """circumbinary_disk.py:272-302"""
+        head = [
+            dict(quantity="time"),
+            dict(quantity="mdot", which_mass=1, accretion=True),
+            dict(quantity="mdot", which_mass=2, accretion=True),
+        ]
+        if self.which_diagnostics == "kitp":
+            return head + [
+                dict(quantity="torque", which_mass="both", gravity=True),
+                dict(quantity="torque", which_mass="both", gravity=True, radial_cut=(1.0, self.domain_radius)),
+                dict(quantity="sigma_m1"),
+                dict(quantity="eccentricity_vector", radial_cut=(1.0, 6.0)),
+            ]
+        return head + [
+            dict(quantity=q, which_mass=m, **{term: True})
+            for m in (1, 2) for q in ("fx", "fy") for term in ("gravity", "accretion")
+        ]
+
+    @property
+    def physics(self):
+        """circumbinary_disk.py:304-318"""
+        return dict(
+            eos_type=EquationOfState.LOCALLY_ISOTHERMAL,
+            mach_number=self.mach_number,
+            point_mass_function=self.point_masses,
+            buffer_is_enabled=self.buffer_is_enabled,
+            buffer_driving_rate=100.0,
+            buffer_onset_width=1.0,
+            viscosity_coefficient=self.nu,
+            viscosity_model=ViscosityModel.CONSTANT_NU if self.nu > 0.0 else ViscosityModel.NONE,
+            diagnostics=self.diagnostics,
+        )
+
+    @property
+    def solver(self):
+        return "cbdisodg_2d" if self.use_dg else "cbdiso_2d"  # circumbinary_disk.py:320-322
+
+    @property
+    def orbital_elements(self):
+        return OrbitalElements(
+            semimajor_axis=1.0, total_mass=1.0, mass_ratio=self.mass_ratio, eccentricity=self.eccentricity
+        )
+
+    def point_masses(self, time):
+        """circumbinary_disk.py:345-372"""
+        common = dict(
+            softening_length=self.softening_length,
+            sink_model=SinkModel[self.sink_model.upper()],
+            sink_rate=self.sink_rate,
+            sink_radius=self.sink_radius,
+        )
+        if self.single_point_mass:
+            return PointMass(mass=1.0, **common)
+        return tuple(PointMass(**common, **body._asdict()) for body in self.orbital_elements.orbital_state(time))
+
+
 class CylindricalExplosion(Setup):
     eos = "isothermal"
     smooth = 6.0
+    use_dg = False
 
     default_end_time = 0.3
     default_resolution = 200
@@ -223,6 +372,8 @@ class CylindricalExplosion(Setup):
     def validate(self):
         if self.eos not in ("isothermal", "gamma-law"):
             raise ValueError(f"eos must be isothermal or gamma-law, got {self.eos}")
+        if self.use_dg and not self.is_isothermal:
+            raise ValueError("DG mode is only available for eos=isothermal")  # simple2d.py:113-114
 
     @property
     def is_isothermal(self):
@@ -257,7 +408,9 @@ class CylindricalExplosion(Setup):
 
     @property
     def solver(self):
-        return "cbdiso_2d" if self.is_isothermal else "cbdgam_2d"
+        if self.is_isothermal:
+            return "cbdisodg_2d" if self.use_dg else "cbdiso_2d"  # simple2d.py:94
+        return "cbdgam_2d"
 
 
 class UniformPolar(Setup):
@@ -453,7 +606,8 @@ class EnvelopeShock(Setup):
 
 
 SETUPS = {
-    "circumbinary-disk": CircumbinaryDisk, "cylindrical-explosion": CylindricalExplosion,
+    "circumbinary-disk": CircumbinaryDisk, "kitp-code-comparison": KitpCodeComparison,
+    "cylindrical-explosion": CylindricalExplosion,
     "uniform-polar": UniformPolar, "envelope-shock": EnvelopeShock,
 }
 

@@ -20,9 +20,10 @@ def register_solver_extension(solver_name, solver_module):
 
 
 def make_solver(name, physics, options, **kwargs):
-    from . import cbdgam_2d, cbdiso_2d, srhd_2d
+    from . import cbdgam_2d, cbdiso_2d, cbdisodg_2d, srhd_2d
 
-    solvers = dict(cbdiso_2d=cbdiso_2d, cbdgam_2d=cbdgam_2d, srhd_2d=srhd_2d, **extension_solvers)
+    solvers = dict(cbdiso_2d=cbdiso_2d, cbdgam_2d=cbdgam_2d, srhd_2d=srhd_2d, cbdisodg_2d=cbdisodg_2d,
+                   **extension_solvers)
     if name not in solvers:
         raise SolverInitializationError(f"no solver named {name}; this package builds {sorted(solvers)}")
     try:

@@ -639,23 +639,24 @@ class SolverBase:
         caller can update halo-independent rows meanwhile.
         """
         local = {k: p for k, p in zip(self.local_ids, self.patches)}
+        ng = self.num_guard
         ops = []
         for k, p in local.items():
             lower, upper = self._neighbors(k)
             pc = getattr(p, array)
             if lower is not None and lower in local:
                 with p.execution_context:
-                    pc[:NG].copy_(getattr(local[lower], array)[-2 * NG:-NG], non_blocking=True)
+                    pc[:ng].copy_(getattr(local[lower], array)[-2 * ng:-ng], non_blocking=True)
             if upper is not None and upper in local:
                 with p.execution_context:
-                    pc[-NG:].copy_(getattr(local[upper], array)[NG:2 * NG], non_blocking=True)
+                    pc[-ng:].copy_(getattr(local[upper], array)[ng:2 * ng], non_blocking=True)
             # A message is named by the guard slab it fills: (destination patch, 0 lower | 1 upper).
             if upper is not None and upper not in local:
-                ops.append(((upper, 0), "send", pc[-2 * NG:-NG], self.owner(upper)))
-                ops.append(((k, 1), "recv", pc[-NG:], self.owner(upper)))
+                ops.append(((upper, 0), "send", pc[-2 * ng:-ng], self.owner(upper)))
+                ops.append(((k, 1), "recv", pc[-ng:], self.owner(upper)))
             if lower is not None and lower not in local:
-                ops.append(((lower, 1), "send", pc[NG:2 * NG], self.owner(lower)))
-                ops.append(((k, 0), "recv", pc[:NG], self.owner(lower)))
+                ops.append(((lower, 1), "send", pc[ng:2 * ng], self.owner(lower)))
+                ops.append(((k, 0), "recv", pc[:ng], self.owner(lower)))
         # Between two ranks, messages are matched in posting order (RCCL has no tags).  Posting in
         # the order of the message names on both sides keeps the pairs aligned also when a rank
         # exchanges several slabs with the same peer (two ranks, several patches, wrap-around halos).
@@ -699,19 +700,20 @@ class SolverBase:
         on both edges in j (which also fills the corners).
         """
         self.finish_halo_exchange(self.start_halo_exchange(array))
+        ng = self.num_guard
         for p in self.patches:
             pc = getattr(p, array)
             with p.execution_context:
                 if p.first:
-                    for i in range(NG):
-                        pc[i] = pc[NG]
+                    for i in range(ng):
+                        pc[i] = pc[ng]
                 if p.last:
-                    for i in range(pc.shape[0] - NG, pc.shape[0]):
-                        pc[i] = pc[-NG - 1]
-                for j in range(NG):
-                    pc[:, j] = pc[:, NG]
-                for j in range(pc.shape[1] - NG, pc.shape[1]):
-                    pc[:, j] = pc[:, -NG - 1]
+                    for i in range(pc.shape[0] - ng, pc.shape[0]):
+                        pc[i] = pc[-ng - 1]
+                for j in range(ng):
+                    pc[:, j] = pc[:, ng]
+                for j in range(pc.shape[1] - ng, pc.shape[1]):
+                    pc[:, j] = pc[:, -ng - 1]
 
     def synchronize(self):
         if self.backend.mode == "hip":

@@ -19,6 +19,12 @@ KernelInvocation, to_ctypes, the solvers, set_bc, the RK schedule -- is the
 reference's code, unmodified.
 
 Fixtures:
+  dg_disk_32.npz               cbdisodg_2d: kitp-code-comparison with use_dg, 32^2, 10 RK2 steps (limiter on, viscosity,
+                               buffer, sinks resolved by the coarse mesh)
+  dg_disk_48_p3_rk3.npz        same solver, eccentric unequal binary, rk_order 3, 3 patches
+  dg_explosion_40.npz          cylindrical-explosion with use_dg, 40^2, 12 steps (the limiter's troubled zones)
+  dg_explosion_40_nolimit.npz  same with limit_slopes off, 2 patches
+                        dg fixtures store the weights (initial, final), dt[], time[], model and options (JSON).
   kepler.npz            point masses at 50 times for (e, q) in {0, 0.3} x {1, 0.2}
   iso_disk_64.npz       circumbinary-disk, isothermal, 64^2, 20 RK2 steps, 1 patch
   iso_disk_128_p4.npz   same at 128^2 on 4 patches (== 1 patch bitwise)
@@ -61,6 +67,7 @@ def reference_modules():
     import sailfish.setups  # noqa: F401  (registers setup classes)
     import sailfish.solvers.cbdgam_2d as ref_gam
     import sailfish.solvers.cbdiso_2d as ref_iso
+    import sailfish.solvers.cbdisodg_2d as ref_dg
     import sailfish.solvers.srhd_2d as ref_srhd
     from sailfish.setup_base import SetupBase
     from sailfish.solvers import make_solver
@@ -69,7 +76,7 @@ def reference_modules():
         def load_cpu_module(self, code, name, mode="cpu", define_macros=dict()):
             import numpy
 
-            solver = [n for n in ("cbdiso_2d", "cbdgam_2d", "srhd_2d") if f"MODULE: {n}" in code][0]
+            solver = [n for n in ("cbdiso_2d", "cbdgam_2d", "srhd_2d", "cbdisodg_2d") if f"MODULE: {n}" in code][0]
             suffix = ""
             if solver == "srhd_2d":
                 # the macro configurations oracle/build_ref.py compiles (define_macros, srhd_2d.py:225-233)
@@ -81,6 +88,7 @@ def reference_modules():
     ref_iso.Library = RefLibrary
     ref_gam.Library = RefLibrary
     ref_srhd.Library = RefLibrary
+    ref_dg.Library = RefLibrary
     return SetupBase, make_solver
 
 
@@ -175,6 +183,15 @@ def run_srhd(SetupBase, make_solver, setup_name, resolution, steps, model=None, 
                 model=np.array(json.dumps(model or {})), options=np.array(json.dumps(options or {})))
 
 
+def run_dg(SetupBase, make_solver, setup_name, resolution, steps, model=None, options=None, num_patches=1):
+    import json
+
+    data = run_reference(SetupBase, make_solver, setup_name, resolution, steps, model, options, num_patches)
+    data["model"] = np.array(json.dumps(model or {}))
+    data["options"] = np.array(json.dumps(options or {}))
+    return data
+
+
 def kepler_fixture(SetupBase):
     rows = []
     times = np.concatenate([np.linspace(0.0, 13.0, 40), [0.1, 1e-3, 100.7, 6.283185307179586, 31.4, 1e3, 2.5, 7.7, 19.9, 50.0]])
@@ -215,6 +232,14 @@ def main():
                                        model=dict(polar_extent=0.5, u_shell=0.0, jet_energy=1e-3, jet_theta=0.3))
     out["srhd_envelope_rk3_theta2"] = srhd("envelope-shock", 32, 6, model=dict(polar_extent=0.25, expand=False),
                                            options=dict(rk_order=3, plm_theta=2.0, mach_ceiling=100.0))
+    dg = lambda *a, **k: run_dg(SetupBase, make_solver, *a, **k)
+    out["dg_disk_32"] = dg("kitp-code-comparison", 32, 10, model=dict(use_dg=True, domain_radius=4.0, sink_radius=0.2))
+    out["dg_disk_48_p3_rk3"] = dg("kitp-code-comparison", 48, 6, num_patches=3, options=dict(rk_order=3),
+                                  model=dict(use_dg=True, domain_radius=3.0, sink_radius=0.2, eccentricity=0.3,
+                                             mass_ratio=0.5, sink_model="torque_free"))
+    out["dg_explosion_40_nolimit"] = dg("cylindrical-explosion", 40, 12, model=dict(use_dg=True),
+                                        options=dict(limit_slopes=False), num_patches=2)
+    out["dg_explosion_40"] = dg("cylindrical-explosion", 40, 12, model=dict(use_dg=True))
     for name, data in out.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
         print(name, data["final"].shape if "final" in data else data["values"][:3],

@@ -150,6 +150,9 @@ class OracleLibrary:
     def _sfhip_srhd_2d_failures(self, shape, kw, args):
         kw["out"][0] = float(self.orc.dll.sfo_srhd_2d_failures()) if self.orc.prefix == "sfo_" else 0.0
 
+    def _sfhip_max_nonneg(self, shape, kw, args):
+        kw["out"][0] = float(_np(kw["x"]).reshape(-1)[: shape[0]].max())
+
     def _sfhip_timestep(self, shape, kw, args):
         with np.errstate(divide="ignore"):  # amax == 0 gives inf on the device too
             kw["dt_out"][0] = float(np.float64(kw["dx"]) / np.float64(kw["wavespeed_max"][0]) * np.float64(kw["cfl"]))
@@ -216,6 +219,55 @@ class OracleLibrary:
         prim = _np(kw["primitive"])
         ws = np.zeros(prim.shape[:2])
         self.orc.call("cbdgam_2d_wavespeed", shape, prim, ws, kw["gamma_law_index"])
+        self._fold(kw["wavespeed_max"], float(ws.max()), 2)
+
+    # -- cbdisodg (one guard zone, weights (ni + 2, nj + 2, 3, 3, 3)) ------------
+    @staticmethod
+    def _dg_clamped(w, lo, hi, cj):
+        w = w.copy()
+        if lo:
+            w[0] = w[1]
+        if hi:
+            w[-1] = w[-2]
+        if cj:
+            w[:, 0] = w[:, 1]
+            w[:, -1] = w[:, -2]
+        return w
+
+    def _sfhip_cbdisodg_2d_limit(self, shape, kw, args):
+        w1 = self._dg_clamped(_np(kw["weights1"]), kw["clamp_lower_i"], kw["clamp_upper_i"], kw["clamp_j"])
+        out = np.zeros_like(w1)
+        self.orc.call("cbdisodg_2d_slope_limit", shape, 0.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, w1, out)
+        i0, i1 = kw["i_begin"] + 1, kw["i_end"] + 1
+        _np(kw["weights2"])[i0:i1, 1:-1] = out[i0:i1, 1:-1]
+
+    def _sfhip_cbdisodg_2d_stage(self, shape, kw, args):
+        w1 = self._dg_clamped(_np(kw["weights1"]), kw["clamp_lower_i"], kw["clamp_upper_i"], kw["clamp_j"])
+        out = _np(kw["weights2"]).copy()  # the three slots outside the scheme keep what the buffer held
+        ref_args = list(args[:40 - 2])  # the 38 arguments after (ni, nj) shared with cbdisodg_2d_advance_rk
+        ref_args[4], ref_args[5], ref_args[6] = _np(kw["weights0"]).copy(), w1, out
+        if kw["dt_device"] is not None:
+            ref_args[36] = float(kw["dt_device"][0])
+        self.orc.call("cbdisodg_2d_advance_rk", shape, *ref_args)
+        i0, i1 = kw["i_begin"] + 1, kw["i_end"] + 1
+        _np(kw["weights2"])[i0:i1, 1:-1] = out[i0:i1, 1:-1]
+        if kw["want_wavespeed"]:
+            ws = np.zeros(w1.shape[:2])
+            self.orc.call(
+                "cbdisodg_2d_wavespeed", shape, *args[0:4], kw["soundspeed2"], kw["mach_squared"], kw["eos_type"],
+                kw["wx1"], kw["wy1"], 0.0, 0.0, kw["wmass1"], kw["wsoftening_length1"], 0.0, 0.0, 0,
+                kw["wx2"], kw["wy2"], 0.0, 0.0, kw["wmass2"], kw["wsoftening_length2"], 0.0, 0.0, 0,
+                kw["velocity_ceiling"], out, ws)
+            self._fold(kw["wavespeed_max"], float(ws[i0:i1, 1:-1].max()), kw["want_wavespeed"])
+
+    def _sfhip_cbdisodg_2d_max_wavespeed(self, shape, kw, args):
+        w = _np(kw["weights"])
+        ws = np.zeros(w.shape[:2])
+        self.orc.call(
+            "cbdisodg_2d_wavespeed", shape, *args[0:7],
+            kw["x1"], kw["y1"], 0.0, 0.0, kw["mass1"], kw["softening_length1"], 0.0, 0.0, 0,
+            kw["x2"], kw["y2"], 0.0, 0.0, kw["mass2"], kw["softening_length2"], 0.0, 0.0, 0,
+            kw["velocity_ceiling"], w, ws)
         self._fold(kw["wavespeed_max"], float(ws.max()), 2)
 
 
