@@ -35,11 +35,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # Algorithmic bytes per zone: a stage reads p and writes p' (NCONS fp64 each); a stage
 # with a != 0 also reads the u^n source at the zone centre.  RK2 zone-update = one of each.
-NCONS = {"iso": 3, "gam": 4, "srhd": 4}
+NCONS = {"iso": 3, "gam": 4, "srhd": 4, "dg": 3}
 # srhd_2d, fused stages (sfhip_srhd_2d_stage): a stage reads the primitives and the conserved state (and u^n
 # when rk_param != 0) and writes the updated state, its floored copy and its primitives: 5 or 6 arrays of 32 B
 # per zone; RK2 zone-update = 11 x 32 B.  (The reference's sequence moves 18 arrays: 576 B.)
 SRHD_BYTES_PER_ZONE_UPDATE = 11 * 32.0
+# cbdisodg_2d: a zone is 3 fields x 6 Legendre weights (stored 3 x 9).  Per RK stage the limiter copies all 27
+# doubles (216 B in, 216 B out, as the reference's kernel does) and the update reads u^n and w and writes w'
+# (18 used doubles each, 432 B): 864 B per stage, RK2 zone-update = 1728 B.
+DG_BYTES_PER_ZONE_UPDATE = 2 * 864.0
 
 
 def parse_args():
@@ -48,7 +52,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--resolution", type=int, default=None, help="zones per side (default 4096*sqrt(gpus))")
-    ap.add_argument("--solver", default="iso", choices=["iso", "gam", "srhd"])
+    ap.add_argument("--solver", default="iso", choices=["iso", "gam", "srhd", "dg"])
     ap.add_argument("--unfused", action="store_true", help="drive the reference-named kernels in reference order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
@@ -79,15 +83,16 @@ def cpu_baseline(setup_name, setup_kwargs, resolution, target_seconds):
         lib = test_oracle.oracle()
         kind = "port"
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
-    if setup.solver == "srhd_2d":
-        # the reference's solver loop is our host mirror of it (pinned bitwise by tests/test_srhd_solver.py)
-        # on the reference's own C kernels
+    if setup.solver in ("srhd_2d", "cbdisodg_2d"):
+        # the reference's solver loop is our host mirror of it (pinned bitwise by tests/test_srhd_solver.py and
+        # tests/test_dg_solver.py) on the reference's own C kernels
         from oracle_backend import OracleBackend
         from sailfish_amd.solvers import make_solver
 
+        extra = dict(fused=False) if setup.solver == "cbdisodg_2d" else {}
         solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=setup.start_time,
-                             backend=OracleBackend(lib), distributed=False)
-        cfl = 0.4
+                             backend=OracleBackend(lib), distributed=False, **extra)
+        cfl = solver.recommended_cfl
     else:
         solver = ref_solver.OracleSolver(setup, mesh, time=0.0, lib=lib)
         cfl = 0.3 if setup.solver == "cbdiso_2d" else 0.1
@@ -147,6 +152,11 @@ def main():
         setup_name, setup_kwargs = "envelope-shock", dict(polar_extent=0.5)
         resolution = args.resolution or int(4800 * math.sqrt(args.gpus))
         extra = dict(fused=not args.unfused)
+    elif args.solver == "dg":
+        # the reference's DG-capable setup; 2048^2 zones x 18 weights on one GPU
+        setup_name, setup_kwargs = "kitp-code-comparison", dict(use_dg=True)
+        resolution = args.resolution or (2048 if args.strong else int(2048 * math.sqrt(args.gpus)) // 8 * 8)
+        extra = dict(fused=not args.unfused)
     else:
         setup_name = "circumbinary-disk"
         resolution = args.resolution or (4096 if args.strong else default_resolution(args.gpus))
@@ -194,10 +204,28 @@ def main():
     BYTES_PER_ZONE_UPDATE = BYTES_STAGE_NO_UN + BYTES_STAGE_UN
     if args.solver == "srhd":
         BYTES_PER_ZONE_UPDATE = SRHD_BYTES_PER_ZONE_UPDATE
+    if args.solver == "dg":
+        BYTES_PER_ZONE_UPDATE = DG_BYTES_PER_ZONE_UPDATE
 
     roofline = None
     kernel_ms = None
-    if use_events and solver.event_log:
+    if use_events and solver.event_log and args.solver == "dg":
+        per_kernel = {}
+        for e in solver.event_log:
+            k = per_kernel.setdefault(e["kernel"], [0.0, 0, 0.0])
+            k[0] += e["start"].elapsed_time(e["stop"])
+            k[1] += 1
+            k[2] += e["zones"] * e["bytes_per_zone"]
+        ms, launches, alg_bytes = per_kernel["dg_advance_kernel"]  # the dominant kernel
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        roofline = dict(
+            bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel="sf::dg_advance_kernel", launches=launches,
+            avg_launch_ms=round(ms / launches, 4), algorithmic_bytes_per_launch=round(alg_bytes / launches),
+            note="fp64 VALU-bound (IEEE division in the viscous fluxes), not HBM-bound: see DESIGN.md",
+        )
+        kernel_ms = {name + "_ms": round(v[0] / v[1], 4) for name, v in per_kernel.items()}
+    elif use_events and solver.event_log:
         alg_bytes = 0.0
         dur_ms = 0.0
         per_kind = {False: [0.0, 0], True: [0.0, 0]}

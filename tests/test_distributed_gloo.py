@@ -147,3 +147,50 @@ def test_srhd_slab_decomposition_over_ranks(name, world, num_patches):
         assert p.exitcode == 0
     for rank, ok, err in results:
         assert ok, (rank, err)
+
+
+def _dg_worker(rank, world, port, name, num_patches, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_dg_solver import USED, build, oracle_backend
+
+        g, mesh, s = build(name, backend=oracle_backend(), mode="host", num_patches=num_patches)
+        assert len(s.patches) == num_patches // world
+        ok = bool(np.array_equal(s.solution, g["initial"]))
+        for dt_ref, t_ref in zip(g["dt"], g["time"]):
+            dt = s.step(float(g["cfl"]))
+            ok &= dt == dt_ref
+            ok &= s.time == t_ref
+        final = s.solution
+        ok &= bool(np.array_equal(final[..., USED], g["final"][..., USED]))
+        queue.put((rank, bool(ok), float(np.abs(final - g["final"])[..., USED].max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,num_patches", [
+    ("dg_disk_48_p3_rk3", 3, 3),         # RK3, limiter: two one-row halo exchanges per stage, middle rank has two peers
+    ("dg_disk_32", 2, 4),                # two patches per rank
+    ("dg_explosion_40_nolimit", 2, 2),   # no limiter: one exchange per stage, buffer rotation keeps u^n without a copy
+])
+def test_dg_slab_decomposition_over_ranks(name, world, num_patches):
+    """cbdisodg_2d over ranks == the reference's run, bitwise (wavespeed MAX all-reduce, device-side dt path)."""
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dg_worker, args=(r, world, port, name, num_patches, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    results = [queue.get(timeout=5) for _ in range(world)]
+    for p in procs:
+        assert p.exitcode == 0
+    for rank, ok, err in results:
+        assert ok, (rank, err)
