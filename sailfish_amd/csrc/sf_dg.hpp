@@ -137,11 +137,45 @@ constexpr DgTables dg_make_tables()
 __constant__ DgTables dg_tab = dg_make_tables();
 
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded division with a shared denominator.
+//
+// The compiler expands an fp64 `a / b` into v_div_scale x2, v_rcp_f64, four FMAs that refine the
+// reciprocal, then `q0 = a r; e = fma(-b, q0, a); q = fma(e, r, q0)` (v_div_fmas) and v_div_fixup:
+// about a dozen VALU instructions, and this kernel divides ~700 times per zone, mostly by a handful
+// of denominators (the surface density of a state, dx, dy, ap - am).  The refinement depends on
+// the denominator alone, so it is done once per denominator here and each quotient costs three
+// instructions.  The result is BIT-IDENTICAL to `a / b` whenever v_div_scale would not rescale
+// and v_div_fixup would not special-case, i.e. for b and a within about 2^-700 .. 2^700 in
+// magnitude (a may also be zero; the zero may come out with the other sign); states outside that
+// range overflow the reference's own arithmetic long before.
+// ---------------------------------------------------------------------------------------------
+struct DgRcp {
+    double den, r;
+};
+
+__device__ __forceinline__ DgRcp dg_rcp(double den)
+{
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return DgRcp{den, r};
+}
+
+__device__ __forceinline__ double dg_div(double num, const DgRcp &d)
+{
+    double q = num * d.r;
+    double e = __builtin_fma(-d.den, q, num);
+    return __builtin_fma(e, d.r, q);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Physics pieces, each the reference's expression tree
 // ---------------------------------------------------------------------------------------------
 
 // gravitational_potential + sound_speed_squared, :56-81, :171-188; masses given as 4 arrays
-__device__ __forceinline__ double dg_cs2(double cs2, double mach2, int eos, double x, double y,
+__device__ __forceinline__ double dg_cs2(double cs2, const DgRcp &mach2, int eos, double x, double y,
                                          const double (&mx)[2], const double (&my)[2], const double (&mm)[2],
                                          const double (&mrs)[2])
 {
@@ -157,15 +191,15 @@ __device__ __forceinline__ double dg_cs2(double cs2, double mach2, int eos, doub
             phi -= mm[p] / sqrt(r2 + mrs[p] * mrs[p]);
         }
     }
-    return -phi / mach2;
+    return dg_div(-phi, mach2);
 }
 
 // conserved_to_primitive, :227-241
-__device__ __forceinline__ void dg_c2p(const double (&u)[3], double (&p)[3], double vmax)
+__device__ __forceinline__ void dg_c2p(const double (&u)[3], const DgRcp &ru0, double (&p)[3], double vmax)
 {
     p[0] = u[0];
-    p[1] = copysign(1.0, u[1]) * min2(fabs(u[1] / u[0]), vmax);
-    p[2] = copysign(1.0, u[2]) * min2(fabs(u[2] / u[0]), vmax);
+    p[1] = copysign(1.0, u[1]) * min2(fabs(dg_div(u[1], ru0)), vmax);
+    p[2] = copysign(1.0, u[2]) * min2(fabs(dg_div(u[2], ru0)), vmax);
 }
 
 // primitive_to_flux, :255-269, with the direction as two 0/1 factors
@@ -179,13 +213,14 @@ __device__ __forceinline__ void dg_flux(const double (&p)[3], const double (&u)[
 }
 
 // The four velocity gradients and three stresses of add_viscous_flux, :326-349 (mu included)
-__device__ __forceinline__ void dg_stress(const double (&u)[3], const double (&ux)[3], const double (&uy)[3], double nu,
-                                          double dx, double dy, double &txx, double &txy, double &tyy)
+__device__ __forceinline__ void dg_stress(const double (&u)[3], const DgRcp &r0, const double (&ux)[3],
+                                          const double (&uy)[3], double nu, const DgRcp &dx, const DgRcp &dy,
+                                          double &txx, double &txy, double &tyy)
 {
-    double dvxdx = 2.0 * (ux[1] / u[0] - u[1] * ux[0] / u[0] / u[0]) / dx;
-    double dvydx = 2.0 * (ux[2] / u[0] - u[2] * ux[0] / u[0] / u[0]) / dx;
-    double dvxdy = 2.0 * (uy[1] / u[0] - u[1] * uy[0] / u[0] / u[0]) / dy;
-    double dvydy = 2.0 * (uy[2] / u[0] - u[2] * uy[0] / u[0] / u[0]) / dy;
+    double dvxdx = dg_div(2.0 * (dg_div(ux[1], r0) - dg_div(dg_div(u[1] * ux[0], r0), r0)), dx);
+    double dvydx = dg_div(2.0 * (dg_div(ux[2], r0) - dg_div(dg_div(u[2] * ux[0], r0), r0)), dx);
+    double dvxdy = dg_div(2.0 * (dg_div(uy[1], r0) - dg_div(dg_div(u[1] * uy[0], r0), r0)), dy);
+    double dvydy = dg_div(2.0 * (dg_div(uy[2], r0) - dg_div(dg_div(u[2] * uy[0], r0), r0)), dy);
     double mu = u[0] * nu;
     double sxx = 4.0 / 3.0 * dvxdx - 2.0 / 3.0 * dvydy;
     double syy = 4.0 / 3.0 * dvydy - 2.0 / 3.0 * dvxdx;
@@ -226,8 +261,9 @@ __device__ __forceinline__ void dg_mass_source(const DgMass &ms, double x, doubl
         du[2] += dt * mdot * prim[2];
         break;
     case 2: {
-        double rhx = ddx / (dr + 1e-12);
-        double rhy = ddy / (dr + 1e-12);
+        const DgRcp rdr = dg_rcp(dr + 1e-12);
+        double rhx = dg_div(ddx, rdr);
+        double rhy = dg_div(ddy, rdr);
         double dv = (prim[1] - ms.vx) * rhx + (prim[2] - ms.vy) * rhy;
         double vxs = dv * rhx + ms.vx;
         double vys = dv * rhy + ms.vy;
@@ -256,8 +292,9 @@ __device__ __forceinline__ void dg_buffer_source(const DgParams &P, double x, do
     if (!P.buffer_on) return;
     double rc = sqrt(x * x + y * y);
     if (rc > P.buf_onset) {
-        double vk = sqrt(P.buf_mass / rc);
-        double u0[3] = {P.buf_sd, P.buf_sd * (-y / rc) * vk, P.buf_sd * (+x / rc) * vk};
+        const DgRcp rrc = dg_rcp(rc);
+        double vk = sqrt(dg_div(P.buf_mass, rrc));
+        double u0[3] = {P.buf_sd, P.buf_sd * dg_div(-y, rrc) * vk, P.buf_sd * dg_div(+x, rrc) * vk};
         double rate = P.buf_rate_prefix * (rc - P.buf_onset) / P.buf_span;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -311,6 +348,7 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
         const double mx[2] = {P.m[0].x, P.m[1].x}, my[2] = {P.m[0].y, P.m[1].y};
         const double mm[2] = {P.m[0].mass, P.m[1].mass}, mrs[2] = {P.m[0].rsoft, P.m[1].rsoft};
         const bool viscous = P.nu > 0.0;
+        const DgRcp rdx = dg_rcp(dx), rdy = dg_rcp(dy), rmach2 = dg_rcp(P.mach2);
 
         double cc[3][DG_K];
         dg_load(weights1 + at, cc);
@@ -336,22 +374,24 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
             const bool high = face & 1, ydir = face >> 1;
             const double x = xc + dg_tab.face_cx[fn] * dx;
             const double y = yc + dg_tab.face_cy[fn] * dy;
-            const double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, x, y, mx, my, mm, mrs);
+            const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, x, y, mx, my, mm, mrs);
             double nb[3][DG_K];
             dg_load(weights1 + at + (face == 0 ? nb_off[0] : face == 1 ? nb_off[1] : face == 2 ? nb_off[2] : nb_off[3]), nb);
             double uo[3], un[3]; // own and neighbour traces
             dg_eval<63>(cc, dg_tab.face_own[fn], uo);
             dg_eval<63>(nb, dg_tab.face_nb[fn], un);
+            const DgRcp ro = dg_rcp(uo[0]), rn = dg_rcp(un[0]);
             double um[3], up[3]; // low-side and high-side states
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 um[q] = high ? uo[q] : un[q];
                 up[q] = high ? un[q] : uo[q];
             }
+            const DgRcp rm = {um[0], high ? ro.r : rn.r}, rp = {up[0], high ? rn.r : ro.r};
             // riemann_hlle, :295-324
             double pl[3], pr[3], fl[3], fr[3], fhat[3];
-            dg_c2p(um, pl, P.vmax);
-            dg_c2p(up, pr, P.vmax);
+            dg_c2p(um, rm, pl, P.vmax);
+            dg_c2p(up, rp, pr, P.vmax);
             const double e0 = ydir ? 0.0 : 1.0, e1 = ydir ? 1.0 : 0.0;
             const double vl = ydir ? pl[2] : pl[1], vr = ydir ? pr[2] : pr[1];
             dg_flux(pl, um, cs2, vl, e0, e1, fl);
@@ -359,9 +399,10 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
             const double cs = sqrt(cs2);
             const double am = min2(0.0, min2(vl - cs, vr - cs));
             const double ap = max2(0.0, max2(vl + cs, vr + cs));
+            const DgRcp rspan = dg_rcp(ap - am);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                fhat[q] = (fl[q] * ap - fr[q] * am - (um[q] - up[q]) * ap * am) / (ap - am);
+                fhat[q] = dg_div(fl[q] * ap - fr[q] * am - (um[q] - up[q]) * ap * am, rspan);
             if (viscous) {
                 // high side first, then low side (:860-869); the face-normal "gradient" IS the trace
                 double to[3], tn[3];
@@ -376,8 +417,8 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                     gxn[q] = ydir ? tn[q] : un[q];
                     gyn[q] = ydir ? un[q] : tn[q];
                 }
-                dg_stress(uo, gxo, gyo, P.nu, dx, dy, oxx, oxy, oyy);
-                dg_stress(un, gxn, gyn, P.nu, dx, dy, nxx, nxy, nyy);
+                dg_stress(uo, ro, gxo, gyo, P.nu, rdx, rdy, oxx, oxy, oyy);
+                dg_stress(un, rn, gxn, gyn, P.nu, rdx, rdy, nxx, nxy, nyy);
                 const double o1 = ydir ? oxy : oxx, o2 = ydir ? oyy : oxy;
                 const double n1 = ydir ? nxy : nxx, n2 = ydir ? nyy : nxy;
                 fhat[1] -= high ? n1 : o1;
@@ -403,17 +444,18 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
             const double x = xc + dg_tab.vol_cx[nd] * dx;
             const double y = yc + dg_tab.vol_cy[nd] * dy;
             const double gw = dg_tab.vol_gw[nd];
-            const double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, x, y, mx, my, mm, mrs);
+            const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, x, y, mx, my, mm, mrs);
             double u[3], p[3], fx[3], fy[3];
             dg_eval<63>(cc, dg_tab.vol_phi[nd], u);
-            dg_c2p(u, p, P.vmax);
+            const DgRcp ru = dg_rcp(u[0]);
+            dg_c2p(u, ru, p, P.vmax);
             dg_flux(p, u, cs2, p[1], 1.0, 0.0, fx);
             dg_flux(p, u, cs2, p[2], 0.0, 1.0, fy);
             if (viscous) {
                 double ux[3], uy[3], txx, txy, tyy;
                 dg_eval<0x38>(cc, dg_tab.vol_dpx[nd], ux); // m >= 1: slots 3, 4, 5
                 dg_eval<0x16>(cc, dg_tab.vol_dpy[nd], uy); // n >= 1: slots 1, 2, 4
-                dg_stress(u, ux, uy, P.nu, dx, dy, txx, txy, tyy);
+                dg_stress(u, ru, ux, uy, P.nu, rdx, rdy, txx, txy, tyy);
                 fx[1] -= txx;
                 fx[2] -= txy;
                 fy[1] -= txy;
@@ -442,12 +484,13 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
         const double *w0 = weights0 + at;
         double *w2 = weights2 + at;
         double avg[3];
+        const DgRcp rvol = dg_rcp(P.cell_volume);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
             for (int k = 0; k < DG_K; ++k) {
                 const int s = q * 9 + DG_SLOT[k];
-                double w = cc[q][k] + (vol[q][k] - srf[q][k]) * 0.5 * dt / P.cell_volume + src[q][k];
+                double w = cc[q][k] + dg_div((vol[q][k] - srf[q][k]) * 0.5 * dt, rvol) + src[q][k];
                 w = (1.0 - P.rk) * w + P.rk * w0[s];
                 w2[s] = w;
                 if (k == 0) avg[q] = w;
@@ -456,8 +499,8 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
 
         if (P.want_ws) { // cbdisodg_2d_wavespeed (:1152-1175) of the zone just written
             double pa[3];
-            dg_c2p(avg, pa, P.vmax);
-            double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, xc, yc, P.wx, P.wy, P.wm, P.wrs);
+            dg_c2p(avg, dg_rcp(avg[0]), pa, P.vmax);
+            double cs2 = dg_cs2(P.cs2, rmach2, P.eos, xc, yc, P.wx, P.wy, P.wm, P.wrs);
             speed = max_speed(pa[1], pa[2], cs2);
         }
     }
@@ -556,8 +599,8 @@ __global__ __launch_bounds__(64) void dg_wavespeed_kernel(DgParams P, const doub
         const double y = P.yl + (j + 0.5) * P.dy;
         const double u[3] = {cc[0], cc[9], cc[18]};
         double p[3];
-        dg_c2p(u, p, P.vmax);
-        const double cs2 = dg_cs2(P.cs2, P.mach2, P.eos, x, y, P.wx, P.wy, P.wm, P.wrs);
+        dg_c2p(u, dg_rcp(u[0]), p, P.vmax);
+        const double cs2 = dg_cs2(P.cs2, dg_rcp(P.mach2), P.eos, x, y, P.wx, P.wy, P.wm, P.wrs);
         speed = max_speed(p[1], p[2], cs2);
         if (wavespeed) wavespeed[(long)(i + 1) * (P.nj + 2) + (j + 1)] = speed;
     }
