@@ -5,8 +5,7 @@ Public surface follows the reference's ``sailfish/solvers/srhd_2d.py``: ``Option
 (:64-68), ``Physics`` (:71-75), ``initial_condition`` (:49-61), ``Patch`` (:78-205) and
 ``Solver`` (:208-407).  The arithmetic is in libsfhip.so (``csrc/sf_srhd.hpp``).
 
-First cut of this solver on the device: the data flow is the
-reference's own -- per RK stage ``conserved_to_primitive`` on every patch, ``set_bc`` on
+The data flow is the reference's own -- per RK stage ``conserved_to_primitive`` on every patch, ``set_bc`` on
 the primitive array, ``advance_rk`` -- with device-resident arrays.  What differs:
 
 * halos between patches are one contiguous slab copy (or an ``isend``/``irecv`` pair
