@@ -5,7 +5,8 @@
 // thread per zone with threadIdx.x along j (the contiguous axis; the reference's gpu mode puts
 // threadIdx.x on i, library.py:75-78, i.e. fully uncoalesced), AoS rows read as 32-byte per-lane
 // loads; advance_rk is a marching-wave kernel (srhd_march_kernel below: slopes once per zone, one
-// HLLC per face, optional fused primitive recovery), its thread-per-zone form kept for A/B timing.  All arithmetic is IEEE fp64 in the reference's operation order
+// HLLC per face, optional fused primitive recovery), its thread-per-zone form kept for A/B timing.
+// All arithmetic is IEEE fp64 in the reference's operation order
 // (contraction off, correctly rounded divide and sqrt), so results are bit-identical to the C
 // path wherever no transcendental is involved.  The only transcendentals on the path are
 //   * sin/cos of the polar face angles: taken from a table the host fills with libm (one
