@@ -25,7 +25,8 @@
 
 namespace sf {
 
-#pragma clang fp contract(off)
+// No FMA contraction anywhere in this file: the library is compiled with -ffp-contract=off
+// (__graft_entry__.HIPCC_FLAGS) and nothing here overrides it; the FMAs of dg_rcp / dg_div are explicit.
 
 constexpr int DG_NW = 27;                         // doubles per zone (3 fields x 3 x 3)
 constexpr int DG_K = 6;                           // used slots per field: m + n < 3
@@ -609,7 +610,5 @@ __global__ __launch_bounds__(64) void dg_wavespeed_kernel(DgParams P, const doub
         if (threadIdx.x == 0) atomic_max_nonneg(wavespeed_max, speed);
     }
 }
-
-#pragma clang fp contract(fast)
 
 } // namespace sf
