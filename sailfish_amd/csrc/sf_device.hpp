@@ -117,6 +117,40 @@ __device__ __forceinline__ double sqrt_from_rsqrt(double x, double y)
     return __builtin_fma(r, 0.5 * y, s);
 }
 
+// ---------------------------------------------------------------------------
+// Correctly rounded fp64 division with a shared denominator (used by the kernels that must
+// reproduce the reference bit for bit: srhd_2d, cbdisodg_2d).
+//
+// The compiler expands `a / b` into v_div_scale x2, v_rcp_f64, four FMAs that refine the
+// reciprocal, then `q0 = a r; e = fma(-b, q0, a); q = fma(e, r, q0)` (v_div_fmas) and
+// v_div_fixup: about a dozen VALU instructions.  The refinement depends on the denominator
+// alone, so it is done once per denominator here and each quotient costs three instructions.
+// The result is BIT-IDENTICAL to `a / b` whenever v_div_scale would not rescale and
+// v_div_fixup would not special-case, i.e. for b and a within about 2^-700 .. 2^700 in
+// magnitude (a may also be zero; the zero may come out with the other sign).  Not for
+// denominators that can be zero, infinite or NaN where the quotient's value matters.
+// ---------------------------------------------------------------------------
+struct ExactRcp {
+    double den, r;
+};
+
+__device__ __forceinline__ ExactRcp exact_rcp(double den)
+{
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return ExactRcp{den, r};
+}
+
+__device__ __forceinline__ double exact_div(double num, const ExactRcp &d)
+{
+    double q = num * d.r;
+    double e = __builtin_fma(-d.den, q, num);
+    return __builtin_fma(e, d.r, q);
+}
+
 // max of a non-negative double over the wave, result valid in every lane
 __device__ __forceinline__ double wave_max_nonneg(double v)
 {

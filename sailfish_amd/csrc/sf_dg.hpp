@@ -137,39 +137,13 @@ constexpr DgTables dg_make_tables()
 
 __constant__ DgTables dg_tab = dg_make_tables();
 
-// ---------------------------------------------------------------------------------------------
-// Correctly rounded division with a shared denominator.
-//
-// The compiler expands an fp64 `a / b` into v_div_scale x2, v_rcp_f64, four FMAs that refine the
-// reciprocal, then `q0 = a r; e = fma(-b, q0, a); q = fma(e, r, q0)` (v_div_fmas) and v_div_fixup:
-// about a dozen VALU instructions, and this kernel divides ~700 times per zone, mostly by a handful
-// of denominators (the surface density of a state, dx, dy, ap - am).  The refinement depends on
-// the denominator alone, so it is done once per denominator here and each quotient costs three
-// instructions.  The result is BIT-IDENTICAL to `a / b` whenever v_div_scale would not rescale
-// and v_div_fixup would not special-case, i.e. for b and a within about 2^-700 .. 2^700 in
-// magnitude (a may also be zero; the zero may come out with the other sign); states outside that
-// range overflow the reference's own arithmetic long before.
-// ---------------------------------------------------------------------------------------------
-struct DgRcp {
-    double den, r;
-};
-
-__device__ __forceinline__ DgRcp dg_rcp(double den)
-{
-    double r = __builtin_amdgcn_rcp(den);
-    double e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return DgRcp{den, r};
-}
-
-__device__ __forceinline__ double dg_div(double num, const DgRcp &d)
-{
-    double q = num * d.r;
-    double e = __builtin_fma(-d.den, q, num);
-    return __builtin_fma(e, d.r, q);
-}
+// Division: the ~700 divisions per zone use a handful of denominators per node (the surface density of
+// a state, dx, dy, a+ - a- ...), so they go through exact_rcp / exact_div (sf_device.hpp): the reciprocal
+// refinement is done once per denominator, each quotient costs three instructions, and the result is
+// bit-identical to `a / b`.
+using DgRcp = ExactRcp;
+__device__ __forceinline__ DgRcp dg_rcp(double den) { return exact_rcp(den); }
+__device__ __forceinline__ double dg_div(double num, const DgRcp &d) { return exact_div(num, d); }
 
 // ---------------------------------------------------------------------------------------------
 // Physics pieces, each the reference's expression tree

@@ -76,18 +76,20 @@ __device__ __forceinline__ int sr_c2p(const double *u1, double *u2, double *p, d
 {
 #pragma clang fp contract(off)
     const int iter_max = 500;
-    const double tol = 1e-12 * (u1[0] + u1[3]) / dv;
-    const double m = u1[0] / dv;
-    const double tau = u1[3] / dv;
-    const double s1 = u1[1] / dv;
-    const double s2 = u1[2] / dv;
+    const ExactRcp rdv = exact_rcp(dv); // shared denominators: same bits as `/`, see sf_device.hpp
+    const double tol = exact_div(1e-12 * (u1[0] + u1[3]), rdv);
+    const double m = exact_div(u1[0], rdv);
+    const double tau = exact_div(u1[3], rdv);
+    const double s1 = exact_div(u1[1], rdv);
+    const double s2 = exact_div(u1[2], rdv);
     const double ss = s1 * s1 + s2 * s2;
     double pr = p[3];
     double w0, f;
     int it = 0;
     for (;;) {
         double et = tau + pr + m;
-        double b2 = min2(ss / et / et, 1.0 - 1e-10);
+        const ExactRcp ret = exact_rcp(et);
+        double b2 = min2(exact_div(exact_div(ss, ret), ret), 1.0 - 1e-10);
         double w2 = 1.0 / (1.0 - b2);
         double w = sqrt(w2);
         double e = (tau + m * (1.0 - w) + pr * (1.0 - w2)) / (m * w);
@@ -104,8 +106,9 @@ __device__ __forceinline__ int sr_c2p(const double *u1, double *u2, double *p, d
         it += 1;
     }
     p[0] = m / w0;
-    p[1] = w0 * s1 / (tau + m + pr);
-    p[2] = w0 * s2 / (tau + m + pr);
+    const ExactRcp ren = exact_rcp(tau + m + pr);
+    p[1] = exact_div(w0 * s1, ren);
+    p[2] = exact_div(w0 * s2, ren);
     p[3] = pr;
     double uu = p[1] * p[1] + p[2] * p[2];
     double e = p[3] / p[0] * 3.0;
@@ -134,8 +137,9 @@ __device__ __forceinline__ void sr_outer_speeds(const double *p, double &lm, dou
     double vv = uu / (1.0 + uu);
     double v2 = vn * vn;
     double k0 = sqrt(a2 * (1.0 - vv) * (1.0 - vv * a2 - v2 * (1.0 - a2)));
-    lm = (vn * (1.0 - a2) - k0) / (1.0 - vv * a2);
-    lp = (vn * (1.0 - a2) + k0) / (1.0 - vv * a2);
+    const ExactRcp rden = exact_rcp(1.0 - vv * a2);
+    lm = exact_div(vn * (1.0 - a2) - k0, rden);
+    lp = exact_div(vn * (1.0 - a2) + k0, rden);
 }
 
 // srhd_2d.c:299-451
@@ -167,10 +171,11 @@ __device__ __forceinline__ void sr_hllc(const double *pl, const double *pr, doub
         return;
     }
     double uh[4], fh[4];
+    const ExactRcp rspan = exact_rcp(ap - am);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        uh[q] = (ur[q] * ap - ul[q] * am + (fl[q] - fr[q])) / (ap - am);
-        fh[q] = (fl[q] * ap - fr[q] * am - (ul[q] - ur[q]) * ap * am) / (ap - am);
+        uh[q] = exact_div(ur[q] * ap - ul[q] * am + (fl[q] - fr[q]), rspan);
+        fh[q] = exact_div(fl[q] * ap - fr[q] * am - (ul[q] - ur[q]) * ap * am, rspan);
     }
     const double un = uh[DIR], fn = fh[DIR];
     const double a = fh[3] + fh[0];
@@ -185,10 +190,11 @@ __device__ __forceinline__ void sr_hllc(const double *pl, const double *pr, doub
     const double vk = left ? vl : vr;
     const double uk0 = left ? ul[0] : ur[0], ukn = left ? ul[DIR] : ur[DIR], ukt = left ? ul[TR] : ur[TR],
                  uk3 = left ? ul[3] : ur[3];
-    const double D = uk0 * (am - vk) / (am - vs);
-    const double E = (am * (uk3 + uk0) - ukn + ps * vs) / (am - vs);
+    const ExactRcp rstar = exact_rcp(am - vs);
+    const double D = exact_div(uk0 * (am - vk), rstar);
+    const double E = exact_div(am * (uk3 + uk0) - ukn + ps * vs, rstar);
     const double Sn = (E + ps) * vs;
-    const double St = ukt * (am - vk) / (am - vs);
+    const double St = exact_div(ukt * (am - vk), rstar);
     const double S1 = DIR == 1 ? Sn : St, S2 = DIR == 1 ? St : Sn;
     const double taus = E - D;
     flux[0] = D * vs - vface * D;
