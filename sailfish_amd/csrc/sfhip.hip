@@ -48,16 +48,20 @@ int env_int(const char *name, int fallback)
     return s && *s ? atoi(s) : fallback;
 }
 
-// Split `nrows` rows into chunks so that the launch has several waves per SIMD
-// on all 256 CUs (1024 SIMDs), without making chunks so short that the 4-row
-// pipeline warm-up dominates.
+// Split `nrows` rows into chunks so that the launch has several waves per SIMD on all 256 CUs
+// (1024 SIMDs), without making chunks so short that the 4-row pipeline warm-up dominates:
+// about 8192 waves (8 workgroups of 4 waves per CU) and at least 32 rows per chunk.  On the
+// device the stage time is flat (+-2 %) between 34 and 69 rows per chunk, for the 4096^2 patch
+// as for the 1448 x 11584 patch of an 8-rank run (tools/sweep_shapes.sh), and ~8 % worse at 94.
+// Small patches, which cannot reach 2 waves per SIMD with 32-row chunks, go down to 8 rows.
 void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
 {
     int rpc = env_int("SFHIP_ROWS_PER_CHUNK", 0);
     if (rpc <= 0) {
         const int target_waves = env_int("SFHIP_TARGET_WAVES", 8192);
         int nc = (target_waves + nstrips - 1) / nstrips;
-        int max_nc = (nrows + 31) / 32; // at least 32 rows per chunk
+        int max_nc = (nrows + 31) / 32;
+        if ((long)max_nc * nstrips < 2048) max_nc = (nrows + 7) / 8;
         if (nc > max_nc) nc = max_nc;
         if (nc < 1) nc = 1;
         rpc = (nrows + nc - 1) / nc;

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--solver", default="iso", choices=["iso", "gam"])
     ap.add_argument("--resolution", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--patches", type=int, default=1,
+                    help="cut the mesh into this many slab patches (all on this GPU) and time patch 0: the launch "
+                         "shape one rank of a multi-GPU run sees")
     args = ap.parse_args()
 
     import torch
@@ -31,7 +34,8 @@ def main():
 
     setup = make_setup("circumbinary-disk", eos="isothermal" if args.solver == "iso" else "gamma-law")
     mesh = setup.mesh(args.resolution)
-    solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, mode="hip")
+    solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, mode="hip",
+                         num_patches=args.patches)
     cfl = solver.recommended_cfl
     for _ in range(5):  # leave the analytic initial state: a developed flow is what the bench times
         solver.step(cfl)
@@ -64,7 +68,7 @@ def main():
             if rep >= 3:
                 times.append(e0.elapsed_time(e1))
         ms = sum(times) / len(times)
-        print(f"{args.solver} {args.resolution}^2 {name}: {ms:.4f} ms  min {min(times):.4f}  "
+        print(f"{args.solver} {ni}x{nj} {name}: {ms:.4f} ms  min {min(times):.4f}  "
               f"{zones * bytes_per_zone / (ms * 1e-3) / 1e9:7.1f} GB/s algorithmic", flush=True)
 
 
