@@ -511,51 +511,95 @@ __device__ __forceinline__ double dg_minmod_truncated(double w1, double w0l, dou
     return (double)(int)pick;
 }
 
+// One wave per 64 consecutive zones of a row.  The zones' 27 doubles are contiguous in memory, so the
+// wave moves its 13.8 KB segment (plus the two neighbouring zones in j) through LDS with unit-stride
+// loads and stores; a lane then works on "its" zone in LDS (stride 27 doubles = 54 banks: conflict-free
+// for 64-bit accesses) and only the five doubles it needs of the two neighbours in i come from global
+// memory with the zone stride.  (Lane-per-zone global accesses reached 3.1 TB/s; this kernel only copies.)
 __global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const double *__restrict__ weights1,
                                                       double *__restrict__ weights2, int clamp_lo, int clamp_hi,
                                                       int clamp_j, int i_begin)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    constexpr int SWEEPS = (66 * DG_NW + 63) / 64; // 28 unit-stride sweeps of the wave cover 66 zones
+    __shared__ double tile[SWEEPS * 64];
+    const int t = threadIdx.x;
+    const int j0 = blockIdx.x * 64;
     const int i = i_begin + blockIdx.y;
-    if (j >= nj) return;
+    const int nvalid = nj - j0 < 64 ? nj - j0 : 64;
     const long sj = DG_NW, si = (long)DG_NW * (nj + 2);
-    const double *cc = weights1 + (i + 1) * si + (j + 1) * sj;
-    const double *li = (clamp_lo && i == 0) ? cc : cc - si;
-    const double *ri = (clamp_hi && i == ni - 1) ? cc : cc + si;
-    const double *lj = (clamp_j && j == 0) ? cc : cc - sj;
-    const double *rj = (clamp_j && j == nj - 1) ? cc : cc + sj;
-    double *out = weights2 + (i + 1) * si + (j + 1) * sj;
+    const double *row = weights1 + (i + 1) * si + (long)j0 * sj; // zone j0 - 1 (a guard zone when j0 == 0)
+    const int nload = (nvalid + 2) * DG_NW;
+    {
+        // all loads are issued before the first wait: addresses past the segment are clamped (the
+        // value lands in an unused part of the tile) instead of branching around the load
+        double staged[SWEEPS];
+#pragma unroll
+        for (int r = 0; r < SWEEPS; ++r) {
+            const int k = t + 64 * r;
+            staged[r] = row[k < nload ? k : nload - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < SWEEPS; ++r)
+            tile[t + 64 * r] = staged[r];
+    }
+    __syncthreads();
 
-    double w[DG_NW];
+    const int j = j0 + t;
+    const bool active = t < nvalid;
+    double wx[3] = {0.0, 0.0, 0.0}, wy[3] = {0.0, 0.0, 0.0};
+    bool change[3] = {false, false, false};
+    if (active) {
+        const double *cc = tile + (t + 1) * DG_NW;
+        const double *lj = (clamp_j && j == 0) ? cc : cc - DG_NW;
+        const double *rj = (clamp_j && j == nj - 1) ? cc : cc + DG_NW;
+        const double *gcc = weights1 + (i + 1) * si + (j + 1) * sj;
+        double li[5], ri[5]; // slots [0][0][0], [0][1][0], [0][2][0], [1][0][0], [2][0][0]
+        const int need[5] = {0, 3, 6, 9, 18};
 #pragma unroll
-    for (int k = 0; k < DG_NW; ++k)
-        w[k] = cc[k];
-
-    const double s3 = 1.7320508075688772, s5 = 2.23606797749979; // sqrt(3.0), sqrt(5.0) correctly rounded
-    const double c00 = w[0];
-    const double big = max2(max2(fabs(c00), fabs(li[0])), max2(fabs(ri[0]), max2(fabs(lj[0]), fabs(rj[0]))));
-    const double a = 4.0 * li[0] + 8.0 * s3 * li[3] + 24.0 * s5 * li[6];
-    const double b = 4.0 * ri[0] - 8.0 * s3 * ri[3] + 24.0 * s5 * ri[6];
-    const double c = 4.0 * lj[0] + 8.0 * s3 * lj[1] + 24.0 * s5 * lj[2];
-    const double d = 4.0 * rj[0] - 8.0 * s3 * rj[1] + 24.0 * s5 * rj[2];
-    const double tci = (fabs(c00 - a / 4.0) + fabs(c00 - b / 4.0) + fabs(c00 - c / 4.0) + fabs(c00 - d / 4.0)) / big;
-    if (tci > 0.1) {
+        for (int k = 0; k < 5; ++k) {
+            li[k] = (clamp_lo && i == 0) ? cc[need[k]] : gcc[need[k] - si];
+            ri[k] = (clamp_hi && i == ni - 1) ? cc[need[k]] : gcc[need[k] + si];
+        }
+        const double s3 = 1.7320508075688772, s5 = 2.23606797749979; // sqrt(3.0), sqrt(5.0) correctly rounded
+        const double c00 = cc[0];
+        const double big = max2(max2(fabs(c00), fabs(li[0])), max2(fabs(ri[0]), max2(fabs(lj[0]), fabs(rj[0]))));
+        const double a = 4.0 * li[0] + 8.0 * s3 * li[1] + 24.0 * s5 * li[2];
+        const double b = 4.0 * ri[0] - 8.0 * s3 * ri[1] + 24.0 * s5 * ri[2];
+        const double c = 4.0 * lj[0] + 8.0 * s3 * lj[1] + 24.0 * s5 * lj[2];
+        const double d = 4.0 * rj[0] - 8.0 * s3 * rj[1] + 24.0 * s5 * rj[2];
+        const double tci = (fabs(c00 - a / 4.0) + fabs(c00 - b / 4.0) + fabs(c00 - c / 4.0) + fabs(c00 - d / 4.0)) / big;
+        if (tci > 0.1) {
+            const double li0[3] = {li[0], li[3], li[4]}, ri0[3] = {ri[0], ri[3], ri[4]};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const double wx = dg_minmod_truncated(w[q * 9 + 3], li[q * 9], w[q * 9], ri[q * 9]);
-            const double wy = dg_minmod_truncated(w[q * 9 + 1], lj[q * 9], w[q * 9], rj[q * 9]);
-            if (wx != w[q * 9 + 3] || wy != w[q * 9 + 1]) {
-#pragma unroll
-                for (int k = 1; k < 9; ++k)
-                    w[q * 9 + k] = 0.0;
-                w[q * 9 + 3] = wx;
-                w[q * 9 + 1] = wy;
+            for (int q = 0; q < 3; ++q) {
+                wx[q] = dg_minmod_truncated(cc[q * 9 + 3], li0[q], cc[q * 9], ri0[q]);
+                wy[q] = dg_minmod_truncated(cc[q * 9 + 1], lj[q * 9], cc[q * 9], rj[q * 9]);
+                change[q] = wx[q] != cc[q * 9 + 3] || wy[q] != cc[q * 9 + 1];
             }
         }
     }
+    __syncthreads(); // every lane has read its neighbours' slopes before anyone overwrites them
+    if (active) {
+        double *cc = tile + (t + 1) * DG_NW;
 #pragma unroll
-    for (int k = 0; k < DG_NW; ++k)
-        out[k] = w[k];
+        for (int q = 0; q < 3; ++q) {
+            if (change[q]) {
+#pragma unroll
+                for (int k = 1; k < 9; ++k)
+                    cc[q * 9 + k] = 0.0;
+                cc[q * 9 + 3] = wx[q];
+                cc[q * 9 + 1] = wy[q];
+            }
+        }
+    }
+    __syncthreads();
+    double *orow = weights2 + (i + 1) * si + (long)(j0 + 1) * sj;
+    const int nstore = nvalid * DG_NW;
+#pragma unroll
+    for (int r = 0; r < DG_NW; ++r) {
+        const int k = t + 64 * r;
+        if (k < nstore) orow[k] = tile[DG_NW + k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
