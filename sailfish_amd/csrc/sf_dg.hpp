@@ -347,11 +347,13 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
         for (int fn = 0; fn < 12; ++fn) {
             const int face = fn & 3;
             const bool high = face & 1, ydir = face >> 1;
+            // the neighbour's weights are requested first: the sound speed and the own trace below
+            // (about 150 instructions) do not need them and cover part of the latency
+            double nb[3][DG_K];
+            dg_load(weights1 + at + (face == 0 ? nb_off[0] : face == 1 ? nb_off[1] : face == 2 ? nb_off[2] : nb_off[3]), nb);
             const double x = xc + dg_tab.face_cx[fn] * dx;
             const double y = yc + dg_tab.face_cy[fn] * dy;
             const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, x, y, mx, my, mm, mrs);
-            double nb[3][DG_K];
-            dg_load(weights1 + at + (face == 0 ? nb_off[0] : face == 1 ? nb_off[1] : face == 2 ? nb_off[2] : nb_off[3]), nb);
             double uo[3], un[3]; // own and neighbour traces
             dg_eval<63>(cc, dg_tab.face_own[fn], uo);
             dg_eval<63>(nb, dg_tab.face_nb[fn], un);
