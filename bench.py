@@ -63,6 +63,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def recorded_traffic(solver, resolution, world):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile.sh (profiles/traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, in KiB, as the MI355X guide prescribes), or None for an unprofiled configuration."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        return json.load(f).get(f"{solver}_{resolution}_{world}")
+
+
 def default_resolution(gpus):
     n = 4096.0 * math.sqrt(gpus)
     return int(n // 8) * 8
@@ -183,7 +193,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    use_events = not args.no_events and not args.unfused and args.solver != "srhd"
+    use_events = not args.no_events and not args.unfused
     if use_events:
         solver.event_log = []
     fence()
@@ -209,20 +219,23 @@ def main():
 
     roofline = None
     kernel_ms = None
-    if use_events and solver.event_log and args.solver == "dg":
+    if use_events and solver.event_log and args.solver in ("dg", "srhd"):
+        dominant = "dg_advance_kernel" if args.solver == "dg" else "srhd_march_kernel"
         per_kernel = {}
         for e in solver.event_log:
             k = per_kernel.setdefault(e["kernel"], [0.0, 0, 0.0])
             k[0] += e["start"].elapsed_time(e["stop"])
             k[1] += 1
             k[2] += e["zones"] * e["bytes_per_zone"]
-        ms, launches, alg_bytes = per_kernel["dg_advance_kernel"]  # the dominant kernel
+        ms, launches, alg_bytes = per_kernel[dominant]
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         roofline = dict(
             bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel="sf::dg_advance_kernel", launches=launches,
+            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=recorded_traffic(setup.solver, resolution, world),
+            kernel="sf::" + dominant, launches=launches,
             avg_launch_ms=round(ms / launches, 4), algorithmic_bytes_per_launch=round(alg_bytes / launches),
-            note="fp64 VALU-bound (IEEE division in the viscous fluxes), not HBM-bound: see DESIGN.md",
+            note="fp64 VALU-bound (IEEE division and square roots kept for bit-exact results), not HBM-bound: "
+                 "see DESIGN.md",
         )
         kernel_ms = {name + "_ms": round(v[0] / v[1], 4) for name, v in per_kernel.items()}
     elif use_events and solver.event_log:
@@ -236,13 +249,7 @@ def main():
             per_kind[e["reads_un"]][0] += ms
             per_kind[e["reads_un"]][1] += 1
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            key = f"{setup.solver}_{resolution}_{world}"
-            traffic = tj.get(key)
+        traffic = recorded_traffic(setup.solver, resolution, world)
         roofline = dict(
             bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,

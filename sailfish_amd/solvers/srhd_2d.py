@@ -143,9 +143,9 @@ class Patch:
                 self.faces, self.conserved1, self.conserved2, self.primitive1, self.polar_extent, self.scale_factor)
             self.conserved1, self.conserved2 = self.conserved2, self.conserved1
 
-    def advance_rk(self, rk_param, dt):
+    def advance_rk(self, rk_param, dt, event_log=None):
         if self.fused:
-            return self.advance_rk_fused(rk_param, dt)
+            return self.advance_rk_fused(rk_param, dt, event_log)
         with self.execution_context:
             self.assert_macros()
             self.lib.srhd_2d_advance_rk[self.shape](
@@ -159,17 +159,29 @@ class Patch:
         self.time = self.time0 * rk_param + (self.time + dt) * (1.0 - rk_param)  # srhd_2d.py:176
         self.conserved1, self.conserved2 = self.conserved2, self.conserved1
 
-    def advance_rk_fused(self, rk_param, dt):
+    def advance_rk_fused(self, rk_param, dt, event_log=None):
         time_next = self.time0 * rk_param + (self.time + dt) * (1.0 - rk_param)  # srhd_2d.py:176
         scale_factor_next = self.scale_factor_initial + self.scale_factor_derivative * time_next
         with self.execution_context:
             self.assert_macros()
-            self.lib.sfhip_srhd_2d_stage[self.shape](
+            fire = self.lib.sfhip_srhd_2d_stage[self.shape].bind(
                 self.faces, self.conserved0, self.primitive1, self.conserved1, self.conserved2,
                 self.polar_extent, self.scale_factor_initial, self.scale_factor_derivative, self.time,
                 rk_param, dt, self.num_first_order_zones,
                 scale_factor_next, self.primitive2, self.conserved3,
             )
+            if event_log is None:
+                fire()
+            else:  # bench.py: HIP events around the launch, on its stream
+                import torch
+
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fire()
+                e1.record()
+                # reads prim, cons (and u^n when rk_param != 0), writes cons', floored cons', prim': 32 B each
+                event_log.append(dict(zones=self.shape[0] * self.shape[1], kernel="srhd_march_kernel",
+                                      bytes_per_zone=(6 if rk_param != 0.0 else 5) * 32.0, start=e0, stop=e1))
         self.time = time_next
         self.conserved1, self.conserved2 = self.conserved2, self.conserved1
         self.recovered = True
@@ -329,7 +341,7 @@ class Solver(SolverBase):
             p.recompute_primitive()
         self.set_bc("primitive1")
         for p in self.patches:
-            p.advance_rk(rk_param, dt)
+            p.advance_rk(rk_param, dt, self.event_log)
 
     def check_failures(self):
         """Raises where the reference's C path would have printed [FATAL] and exited (srhd_2d.c:164-184)."""

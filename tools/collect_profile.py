@@ -25,13 +25,13 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
 lines = []
 fetch, write = [], []
 for kname, counters in sorted(agg.items()):
-    if "stage_kernel" not in kname and "wavespeed" not in kname and "::dg_" not in kname:
+    if "stage_kernel" not in kname and "wavespeed" not in kname and "::dg_" not in kname and "::srhd_" not in kname:
         continue
     lines.append(kname)
     mean = {c: sum(v) / len(v) for c, v in counters.items()}
     for c in sorted(mean):
         lines.append(f"   {c:24s} launches={len(counters[c]):3d} mean={mean[c]:.6g}")
-    if "stage_kernel" in kname or "dg_advance" in kname or "dg_limit" in kname:
+    if "stage_kernel" in kname or "dg_advance" in kname or "dg_limit" in kname or "srhd_march" in kname:
         if "dg_limit" not in kname:  # traffic.json holds the dominant kernel's bytes
             fetch += counters.get("FETCH_SIZE", [])
             write += counters.get("WRITE_SIZE", [])
