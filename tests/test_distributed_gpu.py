@@ -79,3 +79,48 @@ def test_two_ranks_one_gpu(name, use_step):
         rank, err, dt_err = queue.get(timeout=5)
         assert err <= 1e-12, (rank, err)
         assert dt_err <= 1e-13, (rank, dt_err)
+
+
+def _dg_worker(rank, world, port, name, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"  # both ranks on cuda:0
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_dg_solver import build, g_initial, zone_error
+
+        g, mesh, s = build(name, solution=g_initial(name), num_patches=world)
+        worst = 0.0
+        for dt_ref in g["dt"]:
+            dt = s.step(float(g["cfl"]))
+            worst = max(worst, abs(dt - dt_ref) / dt_ref)
+        queue.put((rank, zone_error(s.solution, g["final"]), worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["dg_disk_32", "dg_explosion_40_nolimit"])
+def test_two_ranks_one_gpu_dg(name):
+    """cbdisodg_2d: one-row halo slabs on the comm stream before the limiter and before the update,
+    device-side dt behind the MAX all-reduce; against the reference's run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dg_worker, args=(r, world, port, name, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=100)
+    for p in procs:
+        assert p.exitcode == 0
+    for _ in range(world):
+        rank, err, dt_err = queue.get(timeout=5)
+        assert err <= 1e-12, (rank, err)
+        assert dt_err <= 1e-13, (rank, dt_err)
