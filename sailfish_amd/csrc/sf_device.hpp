@@ -151,6 +151,36 @@ __device__ __forceinline__ double exact_div(double num, const ExactRcp &d)
     return __builtin_fma(e, d.r, q);
 }
 
+// One division by a denominator that is used once: still five instructions fewer than `a / b`
+// (no v_div_scale pair, no v_div_fixup); same validity range as exact_div.
+__device__ __forceinline__ double exact_quot(double num, double den) { return exact_div(num, exact_rcp(den)); }
+
+// Correctly rounded fp64 square root without the compiler's range handling.  `sqrt(x)` expands
+// to a compare + two v_ldexp (rescaling for x < 2^-767), v_rsq_f64, the Goldschmidt iteration
+// below, and a class test + two selects that pass zero and infinity through: 18 instructions.
+// exact_sqrt_pos is the iteration alone (10): BIT-IDENTICAL to sqrt(x) for finite x >= 2^-767
+// (NaN for negative x, as sqrt); x = 0 and x = inf, where the iteration produces NaN, must not
+// reach it.  exact_sqrt0 adds the zero pass-through (+-0 returns itself, as sqrt does).
+__device__ __forceinline__ double exact_sqrt_pos(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, s, 0.5);
+    s = __builtin_fma(s, r, s);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    d = __builtin_fma(-s, s, x);
+    return __builtin_fma(d, h, s);
+}
+
+__device__ __forceinline__ double exact_sqrt0(double x)
+{
+    double s = exact_sqrt_pos(x);
+    return x == 0.0 ? x : s;
+}
+
 // max of a non-negative double over the wave, result valid in every lane
 __device__ __forceinline__ double wave_max_nonneg(double v)
 {

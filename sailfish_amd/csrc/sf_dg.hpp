@@ -163,7 +163,7 @@ __device__ __forceinline__ double dg_cs2(double cs2, const DgRcp &mach2, int eos
             double ddx = x - mx[p];
             double ddy = y - my[p];
             double r2 = ddx * ddx + ddy * ddy;
-            phi -= mm[p] / sqrt(r2 + mrs[p] * mrs[p]);
+            phi -= exact_quot(mm[p], exact_sqrt0(r2 + mrs[p] * mrs[p]));
         }
     }
     return dg_div(-phi, mach2);
@@ -214,9 +214,9 @@ __device__ __forceinline__ void dg_mass_source(const DgMass &ms, double x, doubl
     double ddx = x - ms.x;
     double ddy = y - ms.y;
     double r2 = ddx * ddx + ddy * ddy;
-    double dr = sqrt(r2);
+    double dr = exact_sqrt0(r2);
     double rs2 = r2 + ms.rsoft * ms.rsoft;
-    double fnum = sigma * ms.mass * (1.0 / (rs2 * sqrt(rs2)));
+    double fnum = sigma * ms.mass * exact_quot(1.0, rs2 * exact_sqrt0(rs2));
     double fx = -fnum * ddx;
     double fy = -fnum * ddy;
     double rate = 0.0;
@@ -265,12 +265,12 @@ __device__ __forceinline__ void dg_buffer_source(const DgParams &P, double x, do
                                                  double (&du)[3])
 {
     if (!P.buffer_on) return;
-    double rc = sqrt(x * x + y * y);
+    double rc = exact_sqrt0(x * x + y * y);
     if (rc > P.buf_onset) {
         const DgRcp rrc = dg_rcp(rc);
-        double vk = sqrt(dg_div(P.buf_mass, rrc));
+        double vk = exact_sqrt0(dg_div(P.buf_mass, rrc));
         double u0[3] = {P.buf_sd, P.buf_sd * dg_div(-y, rrc) * vk, P.buf_sd * dg_div(+x, rrc) * vk};
-        double rate = P.buf_rate_prefix * (rc - P.buf_onset) / P.buf_span;
+        double rate = exact_quot(P.buf_rate_prefix * (rc - P.buf_onset), P.buf_span);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             du[q] -= (u[q] - u0[q]) * rate * dt;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
             const double vl = ydir ? pl[2] : pl[1], vr = ydir ? pr[2] : pr[1];
             dg_flux(pl, um, cs2, vl, e0, e1, fl);
             dg_flux(pr, up, cs2, vr, e0, e1, fr);
-            const double cs = sqrt(cs2);
+            const double cs = exact_sqrt0(cs2);
             const double am = min2(0.0, min2(vl - cs, vr - cs));
             const double ap = max2(0.0, max2(vl + cs, vr + cs));
             const DgRcp rspan = dg_rcp(ap - am);

@@ -55,7 +55,9 @@ __device__ __forceinline__ double sr_slope(double yl, double y0, double yr, doub
 }
 
 __device__ __forceinline__ double sr_uu(const double *p) { return p[1] * p[1] + p[2] * p[2]; }
-__device__ __forceinline__ double sr_lorentz(const double *p) { return sqrt(1.0 + sr_uu(p)); }
+// the square roots and single divisions below go through exact_sqrt_* / exact_quot (sf_device.hpp): the
+// compiler's own iterations without its range handling, bit-identical for the magnitudes of a valid state
+__device__ __forceinline__ double sr_lorentz(const double *p) { return exact_sqrt_pos(1.0 + sr_uu(p)); }
 __device__ __forceinline__ double sr_rho_h(const double *p) { return p[0] + p[3] * (1.0 + 1.0 / (SR_GAMMA - 1.0)); }
 
 // srhd_2d.c:90-107
@@ -63,7 +65,7 @@ __device__ __forceinline__ void sr_p2c(const double *p, double *u, double dv)
 {
 #pragma clang fp contract(off)
     double w = sr_lorentz(p);
-    double h = sr_rho_h(p) / p[0];
+    double h = exact_quot(sr_rho_h(p), p[0]);
     double m = p[0] * w;
     u[0] = dv * m;
     u[1] = dv * m * h * p[1];
@@ -90,29 +92,29 @@ __device__ __forceinline__ int sr_c2p(const double *u1, double *u2, double *p, d
         double et = tau + pr + m;
         const ExactRcp ret = exact_rcp(et);
         double b2 = min2(exact_div(exact_div(ss, ret), ret), 1.0 - 1e-10);
-        double w2 = 1.0 / (1.0 - b2);
-        double w = sqrt(w2);
-        double e = (tau + m * (1.0 - w) + pr * (1.0 - w2)) / (m * w);
-        double d = m / w;
-        double h = 1.0 + e + pr / d;
-        double a2 = SR_GAMMA * pr / (d * h);
+        double w2 = exact_quot(1.0, 1.0 - b2);
+        double w = exact_sqrt_pos(w2);
+        double e = exact_quot(tau + m * (1.0 - w) + pr * (1.0 - w2), m * w);
+        double d = exact_quot(m, w);
+        double h = 1.0 + e + exact_quot(pr, d);
+        double a2 = exact_quot(SR_GAMMA * pr, d * h);
         double g = b2 * a2 - 1.0;
         f = d * e * (SR_GAMMA - 1.0) - pr;
-        pr -= f / g;
+        pr -= exact_quot(f, g);
         if (fabs(f) < tol || it == iter_max) {
             w0 = w;
             break;
         }
         it += 1;
     }
-    p[0] = m / w0;
+    p[0] = exact_quot(m, w0);
     const ExactRcp ren = exact_rcp(tau + m + pr);
     p[1] = exact_div(w0 * s1, ren);
     p[2] = exact_div(w0 * s2, ren);
     p[3] = pr;
     double uu = p[1] * p[1] + p[2] * p[2];
-    double e = p[3] / p[0] * 3.0;
-    double emin = uu / (1.0 + uu) / mach_ceiling2;
+    double e = exact_quot(p[3], p[0]) * 3.0;
+    double emin = exact_quot(exact_quot(uu, 1.0 + uu), mach_ceiling2);
     if (e < emin) {
         p[3] = p[0] * emin * (SR_GAMMA - 1.0);
         sr_p2c(p, u2, dv);
@@ -131,12 +133,12 @@ template <int DIR>
 __device__ __forceinline__ void sr_outer_speeds(const double *p, double &lm, double &lp)
 {
 #pragma clang fp contract(off)
-    double a2 = SR_GAMMA * p[3] / sr_rho_h(p);
+    double a2 = exact_quot(SR_GAMMA * p[3], sr_rho_h(p));
     double uu = sr_uu(p);
-    double vn = p[DIR] / sr_lorentz(p);
-    double vv = uu / (1.0 + uu);
+    double vn = exact_quot(p[DIR], sr_lorentz(p));
+    double vv = exact_quot(uu, 1.0 + uu);
     double v2 = vn * vn;
-    double k0 = sqrt(a2 * (1.0 - vv) * (1.0 - vv * a2 - v2 * (1.0 - a2)));
+    double k0 = exact_sqrt0(a2 * (1.0 - vv) * (1.0 - vv * a2 - v2 * (1.0 - a2)));
     const ExactRcp rden = exact_rcp(1.0 - vv * a2);
     lm = exact_div(vn * (1.0 - a2) - k0, rden);
     lp = exact_div(vn * (1.0 - a2) + k0, rden);
@@ -150,7 +152,7 @@ __device__ __forceinline__ void sr_hllc(const double *pl, const double *pr, doub
     double ul[4], ur[4], fl[4], fr[4];
     sr_p2c(pl, ul, 1.0);
     sr_p2c(pr, ur, 1.0);
-    const double vl = pl[DIR] / sr_lorentz(pl), vr = pr[DIR] / sr_lorentz(pr);
+    const double vl = exact_quot(pl[DIR], sr_lorentz(pl)), vr = exact_quot(pr[DIR], sr_lorentz(pr));
     fl[0] = vl * ul[0]; fr[0] = vr * ur[0];
     fl[1] = vl * ul[1] + pl[3] * (DIR == 1); fr[1] = vr * ur[1] + pr[3] * (DIR == 1);
     fl[2] = vl * ul[2] + pl[3] * (DIR == 2); fr[2] = vr * ur[2] + pr[3] * (DIR == 2);
@@ -182,8 +184,8 @@ __device__ __forceinline__ void sr_hllc(const double *pl, const double *pr, doub
     const double b = -(uh[3] + uh[0] + fn);
     const double c = un;
     double vs;
-    if (fabs(a) < 1e-10) vs = -c / b;
-    else vs = (-b - sqrt(b * b - 4.0 * a * c)) / (2.0 * a);
+    if (fabs(a) < 1e-10) vs = exact_quot(-c, b);
+    else vs = exact_quot(-b - exact_sqrt0(b * b - 4.0 * a * c), 2.0 * a);
     const double ps = -a * vs + fn;
     const bool left = vface < vs;
     constexpr int TR = DIR == 1 ? 2 : 1;
@@ -210,13 +212,13 @@ __device__ __forceinline__ double sr_area(double r0, double r1, double s0, doubl
     double R0 = r0 * s0, R1 = r1 * s1;
     double z0 = r0 * c0, z1 = r1 * c1;
     double dR = R1 - R0, dz = z1 - z0;
-    return SR_PI * (R0 + R1) * sqrt(dR * dR + dz * dz);
+    return SR_PI * (R0 + R1) * exact_sqrt0(dR * dR + dz * dz);
 }
 
 __device__ __forceinline__ double sr_volume(double r0, double r1, double c0, double c1) // srhd_2d.c:468-471
 {
 #pragma clang fp contract(off)
-    return -(r1 * r1 * r1 - r0 * r0 * r0) * (c1 - c0) * 2.0 * SR_PI / 3.0;
+    return exact_quot(-(r1 * r1 * r1 - r0 * r0 * r0) * (c1 - c0) * 2.0 * SR_PI, 3.0);
 }
 
 // grid (ceil(nj/256), ni)
