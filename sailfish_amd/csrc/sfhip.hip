@@ -71,6 +71,13 @@ void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
     *nchunks = (nrows + rpc - 1) / rpc;
 }
 
+// waves per workgroup of the marching kernels (their launch bounds allow up to 4)
+int waves_per_block()
+{
+    const int w = env_int("SFHIP_WAVES_PER_BLOCK", 4);
+    return w == 1 || w == 2 ? w : 4;
+}
+
 sf::Mass make_mass(double x, double y, double vx, double vy, double mass, double rsoft, double rate, double rsink, int model)
 {
     sf::Mass m;
@@ -97,7 +104,7 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
     int nchunks;
     plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
     const long waves = (long)nstrips * nchunks;
-    const int wpb = 4;
+    const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
     // epilogue masses identical to the stage's (RK2's last stage): the kernel reuses the source terms' distances
     bool same = P.want_wavespeed != 0;
@@ -130,7 +137,7 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     int nchunks;
     plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
     const long waves = (long)nstrips * nchunks;
-    const int wpb = 4;
+    const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
     auto kernel = P.want_wavespeed ? (P.un_mode ? sf::gam_stage_kernel<true, true> : sf::gam_stage_kernel<true, false>)
                                    : (P.un_mode ? sf::gam_stage_kernel<false, true> : sf::gam_stage_kernel<false, false>);
@@ -820,7 +827,7 @@ static int srhd_advance_impl(int ni, int nj, double *face_positions, double *con
     int rows_per_chunk, nchunks;
     plan_rows(ni, nstrips, &rows_per_chunk, &nchunks);
     const long waves = (long)nstrips * nchunks;
-    const int wpb = 4;
+    const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
     hipLaunchKernelGGL(sf::srhd_march_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
                        conserved_wr, rows_per_chunk, nstrips, nchunks);
