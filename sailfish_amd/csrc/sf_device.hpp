@@ -44,6 +44,13 @@ __device__ __forceinline__ double from_lane_above(double x) // value held by lan
     return __hiloint2double(hi, lo);
 }
 
+// A wave-uniform double moved to scalar registers: a plain operand of vector instructions from then on.
+__device__ __forceinline__ double uniform_value(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
 // C `?:` min/max of the reference (cbdiso_2d.c:16-17); NOT fmin/fmax.
 __device__ __forceinline__ double min2(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double max2(double a, double b) { return a > b ? a : b; }
@@ -179,6 +186,35 @@ __device__ __forceinline__ double exact_sqrt0(double x)
 {
     double s = exact_sqrt_pos(x);
     return x == 0.0 ? x : s;
+}
+
+// exp(x) for the sink profile exp(-(r/r_sink)^4), -700 < x <= 0, reached by a handful of waves per launch.
+// Same range reduction, polynomial and coefficients as the device library's exp (the results are bit-identical
+// in this range; no overflow/underflow handling is needed here), but the 13 constants are read from constant
+// memory inside the call, through a pointer whose origin is hidden from the optimiser: written as exp(), the
+// compiler hoists them out of the march loop into 18 vector registers that every iteration then pays for.
+__constant__ double EXP_TABLE[13] = {
+    0x1.71547652b82fep+0,   // log2(e)
+    -0x1.62e42fefa39efp-1,  // -ln2, high part
+    -0x1.abc9e3b39803fp-56, // -ln2, low part
+    0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22, 0x1.71dee623fde64p-19, 0x1.a01997c89e6b0p-16,
+    0x1.a01a014761f6ep-13, 0x1.6c16c1852b7b0p-10, 0x1.1111111122322p-7, 0x1.55555555502a1p-5,
+    0x1.5555555555511p-3, 0x1.000000000000bp-1,
+};
+
+__device__ __forceinline__ double exp_cold(double x)
+{
+    const double *c = EXP_TABLE;
+    asm volatile("" : "+s"(c));
+    double n = __builtin_rint(x * c[0]);
+    double r = __builtin_fma(n, c[1], x);
+    r = __builtin_fma(n, c[2], r);
+    double p = __builtin_fma(r, c[3], c[4]);
+#pragma unroll
+    for (int k = 5; k < 13; ++k) p = __builtin_fma(r, p, c[k]);
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    return ldexp(p, (int)n);
 }
 
 // max of a non-negative double over the wave, result valid in every lane

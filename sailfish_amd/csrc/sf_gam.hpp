@@ -213,7 +213,7 @@ __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double near2
     if (near && dr < rs4) {
         double q = dr / r_sink;
         double q2 = q * q;
-        rate = cold->sink_rate * exp(-(q2 * q2));
+        rate = cold->sink_rate * exp_cold(-(q2 * q2));
     }
     double y = fast_rsqrt(r2 + r_soft * r_soft);
     double fnum = sigma * m.mass * (y * y * y);

@@ -91,14 +91,17 @@ __device__ __attribute__((noinline)) double iso_exact_speed(const IsoParams *Pk,
 
 // cs2 and cs at a point for the locally isothermal EOS: cs2 = sum m/sqrt(r^2+rs^2) / M^2.
 // `c0`, `c1` are the lane-invariant parts (y - y_p)^2 + rs_p^2 of the two masses.
+// FULL: the caller has established (once, on the host) that the EOS is locally isothermal and both
+// masses are positive, so the tests below are compile-time true; the arithmetic is the same.
+template <bool FULL = false>
 __device__ __forceinline__ void iso_sound_fast(const IsoParams &P, const Mass *m, double x, double c0, double c1,
                                                double &cs2, double &cs)
 {
 #pragma clang fp contract(fast)
-    if (!P.eos_local) { cs2 = P.cs2_uniform; cs = P.cs_uniform; return; }
+    if (!FULL && !P.eos_local) { cs2 = P.cs2_uniform; cs = P.cs_uniform; return; }
     double q = 0.0;
-    if (m[0].mass > 0.0) { double d = x - m[0].x; q += m[0].mass * fast_rsqrt(d * d + c0); }
-    if (m[1].mass > 0.0) { double d = x - m[1].x; q += m[1].mass * fast_rsqrt(d * d + c1); }
+    if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; q += m[0].mass * fast_rsqrt(d * d + c0); }
+    if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; q += m[1].mass * fast_rsqrt(d * d + c1); }
     cs2 = q * P.inv_mach2;
     cs = sqrt_from_rsqrt(cs2, fast_rsqrt(cs2));
 }
@@ -152,7 +155,7 @@ __device__ __forceinline__ double iso_mass_source(double mx, double mmass, doubl
             const int sink_model = cold->sink_model;
             double q = dr / sink_radius;
             double q2 = q * q;
-            double rate = cold->sink_rate * exp(-(q2 * q2));
+            double rate = cold->sink_rate * exp_cold(-(q2 * q2));
             double mdot = 0.0;
             if (rate > 0.0) mdot = -rate * sigma;
             else if (rate < 0.0) mdot = -rate;
@@ -187,10 +190,11 @@ __device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double
 }
 
 // Keplerian buffer, cbdiso_2d.c:213-246
+template <bool FULL = false>
 __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double yc, double yc2, const double *u, double *dc)
 {
 #pragma clang fp contract(fast)
-    if (!P.buf_on) return;
+    if (!FULL && !P.buf_on) return;
     double rc2 = xc * xc + yc2;
     if (rc2 > P.buf_ron2) {
         double rinv = fast_rsqrt(rc2);
@@ -213,7 +217,11 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 // WS: 0 no wavespeed epilogue; 1 epilogue with its own masses P.mw (output time != stage time: RK1, RK3);
 //     2 epilogue when P.mw == P.m bit for bit (last stage of RK2): the softened distances of the
 //     source terms are reused for the sound-speed estimate.
-template <int WS, bool UN>
+// FULL: the benchmark's physics, established on the host -- viscosity on, locally isothermal EOS with both
+//       masses positive, buffer on.  The uniform tests on those flags (and the selects and zero defaults the
+//       untaken sides need) drop out of the march; every floating-point operation is unchanged, so FULL and
+//       generic instantiations give the same bits.
+template <int WS, bool UN, bool FULL>
 __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     if (I1 > NG + P.i_end) I1 = NG + P.i_end;
     const int rlo = P.clamp_ilo ? NG : 0;
     const int rhi = P.clamp_ihi ? ni + NG - 1 : ni + 2 * NG - 1;
-    const bool visc = P.nu > 0.0;
+    const bool visc = FULL || P.nu > 0.0;
     const double hnu = P.half_nu;
     // lane-invariant pieces of the distances to the two masses
     const double dyc0 = yc - P.m[0].y, dyc1 = yc - P.m[1].y;
@@ -274,161 +282,191 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     double quarter = 0.25;
     asm volatile("" : "+s"(quarter));
 
-    double pa[3] = {1, 0, 0}, pb[3] = {1, 0, 0}, pc[3];
-    double gyb[3] = {0, 0, 0};
+    // dt/dx and dt/dy, wave-uniform: formed once (dt may have come from device memory) and held in SGPRs
+    const double kx = uniform_value(P.inv_dx * P.dt), ky = uniform_value(P.inv_dy * P.dt);
+
+    double pa[3], pb[3], pc[3];
+    double gyb[3], gyc[3];
     double pmx[3] = {1, 0, 0}, txx = 0, txy = 0;
-    double Fp[3] = {0, 0, 0}, dGp[3] = {0, 0, 0};
+    // what the row in flight has collected so far of -(dF/dx + dG/dy) dt: its lower x-face flux and its
+    // y-flux difference.  The upper x-face flux is subtracted when the next iteration has evaluated it.
+    // (Every row goes through the same operations, so a zone's bits do not depend on chunk boundaries.)
+    double acc[3] = {0, 0, 0};
     double amax = 0.0;            // exact running maximum of this lane
     double athr = P.ws_floor;     // what an estimate has to reach to be worth the exact evaluation
 
-    // software prefetch: row r+1 (and the u^n source of the row updated next) is requested one
-    // iteration ahead so its HBM latency overlaps this iteration's arithmetic
+    // The window is filled before the march: rows I0-2, I0-1, I0 with the y-slopes of the middle one (no
+    // operation here can contract, so these slopes have the bits the loop would have given them).
+    // Software prefetch: a row is requested one iteration before it enters the window.
     double pn[3], un[3] = {0, 0, 0};
+    auto row = [&](int r) { return prd + (r < rlo ? rlo : (r > rhi ? rhi : r)) * si + col; };
     {
-        int rl = I0 - 2 < rlo ? rlo : (I0 - 2 > rhi ? rhi : I0 - 2);
-        const double *src = prd + rl * si + col;
-        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
+        const double *s0 = row(I0 - 2), *s1 = row(I0 - 1), *s2 = row(I0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { pa[q] = s0[q]; pb[q] = s1[q]; pc[q] = s2[q]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gyb[q] = plm2<18>(from_lane_below(pb[q]), pb[q], from_lane_above(pb[q]));
+            gyc[q] = plm2<18>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]));
+        }
+        // All three rows have to have arrived before the march starts: a load still pending on the loop's
+        // entry edge makes the compiler wait for it inside the loop, in every iteration, behind the
+        // requests just issued there.
+#pragma unroll
+        for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pa[q]));
     }
     constexpr bool want_un = UN;
     const long ucol = (long)(J < nj + 2 * NG ? J : nj + 2 * NG - 1) * sj;
 
-    for (int r = I0 - 2; r <= I1 + 1; ++r) {
-        pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2];
-        if (r < I1 + 1) {
-            int rn = r + 1;
-            int rl = rn < rlo ? rlo : (rn > rhi ? rhi : rn);
-            const double *src = prd + rl * si + col;
+    // One iteration of the march; on entry `pc` holds row r.  The first two iterations only bring the
+    // pipeline up (faces of rows I0-1 and I0; nothing to update yet: `upd` false).  There is ONE instance of
+    // the face arithmetic, so a zone's bits cannot depend on where chunk or patch boundaries fall (two
+    // instances -- bring-up and steady state -- were tried: the compiler contracts them differently).
+    //
+    // Order of the vector-memory traffic.  Loads and stores share one in-order counter (vmcnt) on gfx9, and
+    // hipcc, which assumes that a load and a pending store may complete in either order, waits for
+    // vmcnt(0) at the first use of a loaded value whenever a store is outstanding.  With the stores issued
+    // in the update block, a few instructions before the next row's first use, every iteration stalled for
+    // the stores' round trip.  Here the row just updated is stored as the LAST thing of an iteration, after
+    // the requested row has been put to its first use (its y-slopes, which is what makes the compiler
+    // wait for it there), and the next requests follow as the first thing of the next iteration: whatever a
+    // wait drains is then most of an iteration old.
+#pragma unroll 1
+    for (int r = I0; r <= I1 + 1; ++r) {
+        const bool upd = r - 2 >= I0;
+        if (upd && want_un) {
+            // u^n of the row updated in this iteration: in flight during both face blocks
+            const double *us = unsrc + (long)(r - 2) * si + ucol;
+            un[0] = us[0]; un[1] = us[1]; un[2] = us[2];
+        }
+        { // (the last iteration's request is never consumed: a clamped, valid row; saves a branch)
+            const double *src = row(r + 1);
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
         }
-
-        // y-slopes of row r from the neighbouring lanes
-        double gyc[3];
+        __builtin_amdgcn_sched_barrier(0); // keep the requests first (the scheduler would sink them by ~150 instructions)
+        // row r-1 now has both neighbours: x-slopes and strain (cbdiso_2d.c:248-263)
+        double gxb[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            gyc[q] = plm2<18>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q])); // 2 x slope
+        for (int q = 0; q < 3; ++q) gxb[q] = plm2<18>(pa[q], pb[q], pc[q]); // 2 x slope
+        double sxx = 0, syy = 0, sxy = 0;
+        if (visc) {
+            double ax = gxb[1] * hidx, by = gyb[2] * hidy;
+            sxx = c43 * ax - c23 * by;
+            syy = c43 * by - c23 * ax;
+            sxy = gxb[2] * hidx + gyb[1] * hidy;
+        }
 
-        if (r >= I0) {
-            // row r-1 now has both neighbours: x-slopes and strain (cbdiso_2d.c:248-263)
-            double gxb[3];
+        const double xf = P.xl + (double)(r - 1 - NG) * P.dx;       // lower x-face of row r-1
+        const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;      // centre of row r-1
+
+        // Both faces are evaluated in every iteration, so that the fluxes are plain locals and the
+        // loop-carried `acc` is written unconditionally.  The first iteration's x-face (row I0-1, whose
+        // lower-side states are not formed yet) and the last one's y-face (row I1) go unused: two face
+        // evaluations per chunk.
+        // x-face between rows r-2 and r-1 (cbdiso_2d.c:536-541, 560-561, 579-582)
+        double F[3], tot[3], out[3];
+        {
+            double ppx[3], c2, cs;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gxb[q] = plm2<18>(pa[q], pb[q], pc[q]); // 2 x slope
-            double sxx = 0, syy = 0, sxy = 0;
+            for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - quarter * gxb[q];
+            iso_sound_fast<FULL>(P, P.m, xf, cyc0, cyc1, c2, cs);
+            iso_hlle<0>(pmx, ppx, c2, cs, F);
             if (visc) {
-                double ax = gxb[1] * hidx, by = gyb[2] * hidy;
-                sxx = c43 * ax - c23 * by;
-                syy = c43 * by - c23 * ax;
-                sxy = gxb[2] * hidx + gyb[1] * hidy;
+                F[1] -= hnu * (txx + pb[0] * sxx);
+                F[2] -= hnu * (txy + pb[0] * sxy);
             }
-
-            double F[3] = {0, 0, 0}, dG[3] = {0, 0, 0};
-            const double xf = P.xl + (double)(r - 1 - NG) * P.dx;       // lower x-face of row r-1
-            const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;      // centre of row r-1
-
-            if (r >= I0 + 1) {
-                // x-face between rows r-2 and r-1 (cbdiso_2d.c:536-541, 560-561, 579-582)
-                double ppx[3], c2, cs;
+        }
+        // row r-2 is complete with its upper face: -(dF/dx + dG/dy) dt (cbdiso_2d.c:593-596)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - quarter * gxb[q];
-                iso_sound_fast(P, P.m, xf, cyc0, cyc1, c2, cs);
-                iso_hlle<0>(pmx, ppx, c2, cs, F);
-                if (visc) {
-                    F[1] -= hnu * (txx + pb[0] * sxx);
-                    F[2] -= hnu * (txy + pb[0] * sxy);
-                }
+        for (int q = 0; q < 3; ++q) tot[q] = __builtin_fma(-F[q], kx, acc[q]);
+        {
+            // y-face below this lane's zone in row r-1 (cbdiso_2d.c:543-546, 562-563, 583-586)
+            double pmy[3], ppy[3], G[3], c2, cs;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                pmy[q] = from_lane_below(pb[q] + quarter * gyb[q]);
+                ppy[q] = pb[q] - quarter * gyb[q];
             }
-            if (want_un && r - 2 >= I0) {
-                // u^n of the row updated at the bottom of this iteration, requested here: the y-face and
-                // source-term arithmetic in between (~250 instructions x 3 waves) covers the latency, and
-                // the three values are not live across the x-face block
-                const double *us = unsrc + (long)(r - 2) * si + ucol;
-                un[0] = us[0]; un[1] = us[1]; un[2] = us[2];
+            iso_sound_fast<FULL>(P, P.m, xcb, cyf0, cyf1, c2, cs);
+            iso_hlle<1>(pmy, ppy, c2, cs, G);
+            if (visc) {
+                double tyx = pb[0] * sxy, tyy = pb[0] * syy;
+                G[1] -= hnu * (from_lane_below(tyx) + tyx);
+                G[2] -= hnu * (from_lane_below(tyy) + tyy);
             }
-            if (r - 1 >= I0 && r - 1 < I1) {
-                // y-face below this lane's zone in row r-1 (cbdiso_2d.c:543-546, 562-563, 583-586)
-                double pmy[3], ppy[3], G[3], c2, cs;
+            // row r-1 so far: its lower x-face flux and its y-flux difference
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    pmy[q] = from_lane_below(pb[q] + quarter * gyb[q]);
-                    ppy[q] = pb[q] - quarter * gyb[q];
-                }
-                iso_sound_fast(P, P.m, xcb, cyf0, cyf1, c2, cs);
-                iso_hlle<1>(pmy, ppy, c2, cs, G);
-                if (visc) {
-                    double tyx = pb[0] * sxy, tyy = pb[0] * syy;
-                    G[1] -= hnu * (from_lane_below(tyx) + tyx);
-                    G[2] -= hnu * (from_lane_below(tyy) + tyy);
-                }
+            for (int q = 0; q < 3; ++q) acc[q] = __builtin_fma(-(from_lane_above(G[q]) - G[q]), ky, F[q] * kx);
+        }
+        if (upd) {
+            // update row r-2 (cbdiso_2d.c:588-602)
+            const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
+            double u[3] = {pa[0], pa[1] * pa[0], pa[2] * pa[0]};
+            double dc[3] = {0.0, 0.0, 0.0};
+            iso_buffer<FULL>(P, xc, yc, yc2, u, dc);
+            const double y0 = iso_mass_source(P.m[0].x, P.m[0].mass, reach0, &Pk->m[0], xc, dyc0, cyc0, P.dt, pa, dc);
+            const double y1 = iso_mass_source(P.m[1].x, P.m[1].mass, reach1, &Pk->m[1], xc, dyc1, cyc1, P.dt, pa, dc);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) dG[q] = from_lane_above(G[q]) - G[q];
+            for (int q = 0; q < 3; ++q) u[q] += dc[q] + tot[q];
+            if (want_un) {
+                double un0 = un[0], un1 = un[1], un2 = un[2];
+                if (P.un_mode == 2) { un1 *= un0; un2 *= un0; } // u^n = p2c(p^n), cbdiso_2d.c:285-298
+                const double b = P.one_minus_a;
+                u[0] = b * u[0] + P.a * un0;
+                u[1] = b * u[1] + P.a * un1;
+                u[2] = b * u[2] + P.a * un2;
             }
-            if (r - 2 >= I0) {
-                // update row r-2 (cbdiso_2d.c:588-602)
-                const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
-                double u[3] = {pa[0], pa[1] * pa[0], pa[2] * pa[0]};
-                double dc[3] = {0.0, 0.0, 0.0};
-                iso_buffer(P, xc, yc, yc2, u, dc);
-                const double y0 = iso_mass_source(P.m[0].x, P.m[0].mass, reach0, &Pk->m[0], xc, dyc0, cyc0, P.dt, pa, dc);
-                const double y1 = iso_mass_source(P.m[1].x, P.m[1].mass, reach1, &Pk->m[1], xc, dyc1, cyc1, P.dt, pa, dc);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    dc[q] -= ((F[q] - Fp[q]) * P.inv_dx + dGp[q] * P.inv_dy) * P.dt;
-                    u[q] += dc[q];
-                }
-                const long c = (long)(r - 2) * si + (long)J * sj;
-                if (want_un) {
-                    double un0 = un[0], un1 = un[1], un2 = un[2];
-                    if (P.un_mode == 2) { un1 *= un0; un2 *= un0; } // u^n = p2c(p^n), cbdiso_2d.c:285-298
-                    const double b = P.one_minus_a;
-                    u[0] = b * u[0] + P.a * un0;
-                    u[1] = b * u[1] + P.a * un1;
-                    u[2] = b * u[2] + P.a * un2;
-                }
-                // primitive recovery with floors (cbdiso_2d.c:268-283)
-                double rho = __builtin_fmax(u[0], P.dfloor);
-                double rinv = fast_rcp(rho);
-                double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
-                double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
-                if (store_lane) {
-                    pwr[c] = rho; pwr[c + 1] = vx; pwr[c + 2] = vy;
-                    if (WS) {
-                        // max(|v-cs|,|v+cs|) == fl(|v| + cs) for cs >= 0, so the zone's speed is
-                        // fl(max(|vx|,|vy|) + cs).  A ~1-ulp estimate of cs filters the zones that
-                        // cannot raise this lane's running maximum; the rest take the IEEE path,
-                        // so the reduced value is bit-identical to cbdiso_2d_wavespeed + max.
-                        double vm = __builtin_fmax(fabs(vx), fabs(vy));
-                        double c2e, cse;
-                        if (WS == 2) {
-                            if (!P.eos_local) cse = P.cs_uniform;
-                            else {
-                                c2e = 0.0;
-                                if (P.m[0].mass > 0.0) c2e += P.m[0].mass * y0;
-                                if (P.m[1].mass > 0.0) c2e += P.m[1].mass * y1;
-                                c2e *= P.inv_mach2;
-                                cse = sqrt_from_rsqrt(c2e, fast_rsqrt(c2e));
-                            }
-                        } else {
-                            iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
+            // primitive recovery with floors (cbdiso_2d.c:268-283)
+            double rho = __builtin_fmax(u[0], P.dfloor);
+            double rinv = fast_rcp(rho);
+            double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
+            double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
+            out[0] = rho; out[1] = vx; out[2] = vy;
+            if (store_lane) {
+                if (WS) {
+                    // max(|v-cs|,|v+cs|) == fl(|v| + cs) for cs >= 0, so the zone's speed is
+                    // fl(max(|vx|,|vy|) + cs).  A ~1-ulp estimate of cs filters the zones that
+                    // cannot raise this lane's running maximum; the rest take the IEEE path,
+                    // so the reduced value is bit-identical to cbdiso_2d_wavespeed + max.
+                    double vm = __builtin_fmax(fabs(vx), fabs(vy));
+                    double c2e, cse;
+                    if (WS == 2) {
+                        if (!FULL && !P.eos_local) cse = P.cs_uniform;
+                        else {
+                            c2e = 0.0;
+                            if (FULL || P.m[0].mass > 0.0) c2e += P.m[0].mass * y0;
+                            if (FULL || P.m[1].mass > 0.0) c2e += P.m[1].mass * y1;
+                            c2e *= P.inv_mach2;
+                            cse = sqrt_from_rsqrt(c2e, fast_rsqrt(c2e));
                         }
-                        if ((vm + cse) * (1.0 + 1e-9) >= athr) {
-                            double sp = iso_exact_speed(Pk, xc, yc, vx, vy);
-                            amax = max2(amax, sp);
-                            athr = max2(athr, amax);
-                        }
+                    } else {
+                        iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
+                    }
+                    if ((vm + cse) * (1.0 + 1e-9) >= athr) {
+                        double sp = iso_exact_speed(Pk, xc, yc, vx, vy);
+                        amax = max2(amax, sp);
+                        athr = max2(athr, amax);
                     }
                 }
             }
-            // slide the window: row r-1 becomes the lower side of the next x-face
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                pmx[q] = pb[q] + quarter * gxb[q];
-                Fp[q] = F[q];
-                dGp[q] = dG[q];
-            }
-            txx = pb[0] * sxx;
-            txy = pb[0] * sxy;
         }
+        // slide the window: row r-1 becomes the lower side of the next x-face
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { gyb[q] = gyc[q]; pa[q] = pb[q]; pb[q] = pc[q]; }
+        for (int q = 0; q < 3; ++q) pmx[q] = pb[q] + quarter * gxb[q];
+        txx = pb[0] * sxx;
+        txy = pb[0] * sxy;
+        // row r+1 enters the window: its y-slopes from the neighbouring lanes (2 x slope)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gyb[q] = gyc[q];
+            gyc[q] = plm2<18>(from_lane_below(pn[q]), pn[q], from_lane_above(pn[q]));
+            pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
+        }
+        __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
+        if (upd && store_lane) {
+            const long c = (long)(r - 2) * si + (long)J * sj;
+            pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2];
+        }
     }
     if (WS) {
         amax = wave_max_nonneg(amax);

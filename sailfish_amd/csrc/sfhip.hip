@@ -112,9 +112,20 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
         same = memcmp(&P.m[k].x, &P.mw[k].x, sizeof(double)) == 0 && memcmp(&P.m[k].y, &P.mw[k].y, sizeof(double)) == 0 &&
                memcmp(&P.m[k].mass, &P.mw[k].mass, sizeof(double)) == 0 &&
                memcmp(&P.m[k].rsoft, &P.mw[k].rsoft, sizeof(double)) == 0;
-    auto kernel = !P.want_wavespeed ? (P.un_mode ? sf::iso_stage_kernel<0, true> : sf::iso_stage_kernel<0, false>)
-                  : same            ? (P.un_mode ? sf::iso_stage_kernel<2, true> : sf::iso_stage_kernel<2, false>)
-                                    : (P.un_mode ? sf::iso_stage_kernel<1, true> : sf::iso_stage_kernel<1, false>);
+    // the full-physics instantiations (see iso_stage_kernel): same arithmetic, flag tests resolved here
+    const bool full = P.nu > 0.0 && P.eos_local && P.m[0].mass > 0.0 && P.m[1].mass > 0.0 && P.buf_on &&
+                      !env_int("SFHIP_GENERIC_STAGE", 0);
+    const int ws = !P.want_wavespeed ? 0 : (same ? 2 : 1);
+    using Kernel = void (*)(sf::IsoParams, const double *, const double *, double *, double *, int, int);
+    static const Kernel table[3][2][2] = {
+        {{sf::iso_stage_kernel<0, false, false>, sf::iso_stage_kernel<0, false, true>},
+         {sf::iso_stage_kernel<0, true, false>, sf::iso_stage_kernel<0, true, true>}},
+        {{sf::iso_stage_kernel<1, false, false>, sf::iso_stage_kernel<1, false, true>},
+         {sf::iso_stage_kernel<1, true, false>, sf::iso_stage_kernel<1, true, true>}},
+        {{sf::iso_stage_kernel<2, false, false>, sf::iso_stage_kernel<2, false, true>},
+         {sf::iso_stage_kernel<2, true, false>, sf::iso_stage_kernel<2, true, true>}},
+    };
+    Kernel kernel = table[ws][P.un_mode ? 1 : 0][full ? 1 : 0];
     hipLaunchKernelGGL(kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
     return check_launch("cbdiso_2d stage launch");
 }
