@@ -136,12 +136,14 @@ __device__ __forceinline__ void gam_mass_source(const Mass &m, double x1, double
 
 // 1/sqrt(sum_p m_p r_p^-3) at a point; c0, c1 = (y - y_p)^2 + 1e-12 precomputed per lane.
 // Multiplying sqrt(p/sigma) by it gives disk_height (cbdgam_2d.c:75-106).
+// FULL: both masses are known (on the host) to be positive, see gam_stage_kernel.
+template <bool FULL = false>
 __device__ __forceinline__ double gam_inv_omega_fast(const Mass *m, double x, double c0, double c1)
 {
 #pragma clang fp contract(fast)
     double om2 = 0.0;
-    if (m[0].mass > 0.0) { double d = x - m[0].x; double y = fast_rsqrt(d * d + c0); om2 += m[0].mass * (y * y * y); }
-    if (m[1].mass > 0.0) { double d = x - m[1].x; double y = fast_rsqrt(d * d + c1); om2 += m[1].mass * (y * y * y); }
+    if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; double y = fast_rsqrt(d * d + c0); om2 += m[0].mass * (y * y * y); }
+    if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; double y = fast_rsqrt(d * d + c1); om2 += m[1].mass * (y * y * y); }
     return fast_rsqrt(om2);
 }
 
@@ -184,13 +186,14 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
 // `eps` = specific internal energy, `h` = disk height (non-constant softening only).
 // `near2` = (4 r_sink)^2 from the host; `cold` addresses the same mass in memory for what only the
 // sink interior needs (loaded there, on demand, instead of occupying SGPRs throughout the march).
+template <bool FULL = false>
 __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double near2, const Mass *cold,
                                                      double x1, double ddy, double dt,
                                                      const double *prim, double eps, double h, double *u,
                                                      int constant_softening)
 {
 #pragma clang fp contract(fast)
-    if (m.sink_model < 1 || m.sink_model > 3) return; // inactive: no gravity either (cbdgam_2d.c:194-201)
+    if (!FULL && (m.sink_model < 1 || m.sink_model > 3)) return; // inactive: no gravity either (cbdgam_2d.c:194-201)
     double sigma = prim[0];
     double ddx = x1 - m.x;
     double r2 = ddx * ddx + ddy * ddy;
@@ -253,10 +256,11 @@ __device__ __attribute__((noinline)) double gam_exact_speed(double vx, double vy
 }
 
 // cbdgam_2d.c:238-276
+template <bool FULL = false>
 __device__ __forceinline__ void gam_buffer_fast(const GamParams &P, double xc, double yc, double yc2, double *u)
 {
 #pragma clang fp contract(fast)
-    if (!P.buf_on) return;
+    if (!FULL && !P.buf_on) return;
     double rc2 = xc * xc + yc2;
     if (rc2 > P.buf_ron2) {
         double rinv = fast_rsqrt(rc2);
@@ -290,7 +294,10 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
     u[3] += sigma * (ec - eps);
 }
 
-template <bool WS, bool UN>
+// FULL: the benchmark's physics, established on the host -- alpha viscosity on, both masses positive with
+//       active sinks, buffer on: the uniform tests on those flags drop out of the march (same arithmetic,
+//       same bits as the generic instantiation; see iso_stage_kernel).
+template <bool WS, bool UN, bool FULL>
 __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
     GamParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
@@ -311,8 +318,8 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
     const int ni = P.ni, nj = P.nj;
     const long sj = 4, si = 4L * (nj + 2 * NG);
     const double gamma = P.gamma;
-    const bool visc = P.alpha > 0.0;
-    const bool hvar = P.any_mass != 0; // disk height varies in space
+    const bool visc = FULL || P.alpha > 0.0;
+    const bool hvar = FULL || P.any_mass != 0; // disk height varies in space
 
     const int J = strip * STRIP + lane;
     int Jld = J;
@@ -342,41 +349,50 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
     double quarter = 0.25;
     asm volatile("" : "+s"(quarter));
 
-    double pa[4] = {1, 0, 0, 1}, pb[4] = {1, 0, 0, 1}, pc[4], pn[4], un[4] = {0, 0, 0, 0};
-    double gyb[4] = {0, 0, 0, 0};
+    // dt/dx and dt/dy, wave-uniform: formed once (dt may have come from device memory) and held in SGPRs
+    const double kx = uniform_value(P.inv_dx * P.dt), ky = uniform_value(P.inv_dy * P.dt);
+
+    double pa[4], pb[4], pc[4], pn[4], un[4] = {0, 0, 0, 0};
+    double gyb[4], gyc[4];
     // carried from row r-2 (the lower side of the next x-face)
     double pmx[4] = {1, 0, 0, 1}, sxxa = 0, sxya = 0, csa = 1, qha = 1, nua = 0;
-    double Fp[4] = {0, 0, 0, 0};  // lower-face flux of row r-2 as that row sees it
-    double dGp[4] = {0, 0, 0, 0}; // (upper - lower) y-flux difference of row r-2
+    // what the row in flight has collected so far of -(dF/dx + dG/dy) dt: its lower x-face flux (as that row
+    // sees it) and its y-flux difference; the upper x-face flux follows in the next iteration (see sf_iso.hpp)
+    double acc[4] = {0, 0, 0, 0};
     double amax = 0.0, athr = P.ws_floor;
 
+    // The window is filled before the march (rows I0-2, I0-1, I0 and the y-slopes of the last two; nothing
+    // here can contract), and all of it has arrived before the loop is entered -- see sf_iso.hpp for this
+    // and for the order of the vector-memory traffic inside an iteration (requests first, stores last).
+    auto row = [&](int r) { return prd + (r < rlo ? rlo : (r > rhi ? rhi : r)) * si + col; };
     {
-        int rl = I0 - 2 < rlo ? rlo : (I0 - 2 > rhi ? rhi : I0 - 2);
-        const double *src = prd + rl * si + col;
-        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+        const double *s0 = row(I0 - 2), *s1 = row(I0 - 1), *s2 = row(I0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pa[q] = s0[q]; pb[q] = s1[q]; pc[q] = s2[q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            gyb[q] = plm2<15>(from_lane_below(pb[q]), pb[q], from_lane_above(pb[q]));
+            gyc[q] = plm2<15>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(pa[q]));
     }
 
-    for (int r = I0 - 2; r <= I1 + 1; ++r) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pc[q] = pn[q];
-        if (r < I1 + 1) {
-            int rn = r + 1;
-            int rl = rn < rlo ? rlo : (rn > rhi ? rhi : rn);
-            const double *src = prd + rl * si + col;
-            pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
-        }
-        if (UN && r - 2 >= I0) {
+#pragma unroll 1
+    for (int r = I0; r <= I1 + 1; ++r) {
+        const bool upd = r - 2 >= I0; // the first two iterations only bring the pipeline up
+        if (UN && upd) {
             // u^n of the row updated at the bottom of this iteration: the whole iteration covers its latency
             const double *us = unsrc + (long)(r - 2) * si + ucol;
             un[0] = us[0]; un[1] = us[1]; un[2] = us[2]; un[3] = us[3];
         }
+        { // (the last iteration's request is never consumed: a clamped, valid row; saves a branch)
+            const double *src = row(r + 1);
+            pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the requests first
 
-        double gyc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            gyc[q] = plm2<15>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q])); // 2 x slope
-
-        if (r >= I0) {
+        {
             double gxb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) gxb[q] = plm2<15>(pa[q], pb[q], pc[q]); // 2 x slope
@@ -396,18 +412,19 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
             const double csb = qhb * P.sqrt_gamma;
             double nub = 0;
             if (visc) // nu = alpha h cs at the zone centre, cbdgam_2d.c:644
-                nub = P.alpha * (hvar ? qhb * gam_inv_omega_fast(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
+                nub = P.alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
 
-            double FR[4] = {0, 0, 0, 0}, FL[4] = {0, 0, 0, 0}, dG[4] = {0, 0, 0, 0};
-
-            if (r >= I0 + 1) {
+            // Both faces are evaluated in every iteration (the first one's x-face and the last one's y-face go
+            // unused), so that the fluxes are plain locals and `acc` is written unconditionally.
+            double FR[4], FL[4], tot[4], out[4];
+            {
                 // x-face between rows r-2 (L) and r-1 (R)
                 double ppx[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ppx[q] = pb[q] - quarter * gxb[q];
                 gam_hlle2_fast<0>(pmx, ppx, csa, csb, P.inv_gm1, FR, FL);
                 if (visc) {
-                    double iof = hvar ? gam_inv_omega_fast(P.m, xf, oyc0, oyc1) : 1.0;
+                    double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, xf, oyc0, oyc1) : 1.0;
                     double nufL = P.alpha * (hvar ? qha * iof : 1.0) * csa; // cbdgam_2d.c:639,645
                     double nufR = P.alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:640,646
                     double txa = pa[0] * sxxa, tya = pa[0] * sxya, txb = pb[0] * sxx, tyb = pb[0] * sxy;
@@ -420,7 +437,10 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                     FL[3] -= 0.5 * (nua * exa + nufR * exb);
                 }
             }
-            if (r - 1 >= I0 && r - 1 < I1) {
+            // row r-2 is complete with its upper face (as that row sees it): -(dF/dx + dG/dy) dt
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tot[q] = __builtin_fma(-FL[q], kx, acc[q]);
+            {
                 // y-face between lane j-1 (L) and this lane (R), row r-1
                 double pmy[4], ppy[4], GR[4], GL[4];
 #pragma unroll
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                     double txl = from_lane_below(txb), tyl = from_lane_below(tyb), exl = from_lane_below(exb);
                     double qhl = from_lane_below(qhb);
                     double nul = from_lane_below(nub);
-                    double iof = hvar ? gam_inv_omega_fast(P.m, xcb, oyf0, oyf1) : 1.0;
+                    double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, xcb, oyf0, oyf1) : 1.0;
                     double nufL = P.alpha * (hvar ? qhl * iof : 1.0) * csl; // cbdgam_2d.c:641,647
                     double nufR = P.alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:642,648
                     GR[1] -= 0.5 * (nufL * txl + nub * txb);
@@ -448,9 +468,9 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                 }
                 // upper face of this zone is the lower face of lane j+1, seen from below
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dG[q] = from_lane_above(GL[q]) - GR[q];
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(-(from_lane_above(GL[q]) - GR[q]), ky, FR[q] * kx);
             }
-            if (r - 2 >= I0) {
+            if (upd) {
                 // update row r-2 (cbdgam_2d.c:669-681)
                 const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
                 const double rinva = fast_rcp(pa[0]);
@@ -460,14 +480,13 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                 u[3] = pa[3] * P.inv_gm1 + 0.5 * pa[0] * (pa[1] * pa[1] + pa[2] * pa[2]);
                 // disk_height at the zone centre is only consumed by non-constant softening
                 double hcc = 1.0;
-                if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast(P.m, xc, oyc0, oyc1);
-                gam_buffer_fast(P, xc, yc, yc2, u);
-                gam_mass_source_fast(P.m[0], P.sink_near2[0], &Pk->m[0], xc, dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
-                gam_mass_source_fast(P.m[1], P.sink_near2[1], &Pk->m[1], xc, dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
+                if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast<FULL>(P.m, xc, oyc0, oyc1);
+                gam_buffer_fast<FULL>(P, xc, yc, yc2, u);
+                gam_mass_source_fast<FULL>(P.m[0], P.sink_near2[0], &Pk->m[0], xc, dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_mass_source_fast<FULL>(P.m[1], P.sink_near2[1], &Pk->m[1], xc, dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
                 gam_cooling_fast(P, pa, eps, rinva, u);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) u[q] -= ((FL[q] - Fp[q]) * P.inv_dx + dGp[q] * P.inv_dy) * P.dt;
-                const long c = (long)(r - 2) * si + (long)J * sj;
+                for (int q = 0; q < 4; ++q) u[q] += tot[q];
                 if (UN) {
                     double w[4] = {un[0], un[1], un[2], un[3]};
                     if (P.un_mode == 2) { // u^n = p2c(p^n), cbdgam_2d.c:347-362
@@ -486,8 +505,8 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                 double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
                 double rho = u[0];
                 if (u[0] < P.dfloor) { rho = P.dfloor; vx = 0.0; vy = 0.0; pres = P.pfloor; }
+                out[0] = rho; out[1] = vx; out[2] = vy; out[3] = pres;
                 if (store_lane) {
-                    pwr[c] = rho; pwr[c + 1] = vx; pwr[c + 2] = vy; pwr[c + 3] = pres;
                     if (WS) {
                         // same filter as the isothermal kernel: a ~1-ulp estimate decides which zones
                         // get the IEEE evaluation, so the reduced maximum is bit-exact
@@ -501,15 +520,21 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                pmx[q] = pb[q] + quarter * gxb[q];
-                Fp[q] = FR[q];
-                dGp[q] = dG[q];
-            }
+            for (int q = 0; q < 4; ++q) pmx[q] = pb[q] + quarter * gxb[q];
             sxxa = sxx; sxya = sxy; csa = csb; qha = qhb; nua = nub;
-        }
+            // row r+1 enters the window: its y-slopes from the neighbouring lanes (2 x slope)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { gyb[q] = gyc[q]; pa[q] = pb[q]; pb[q] = pc[q]; }
+            for (int q = 0; q < 4; ++q) {
+                gyb[q] = gyc[q];
+                gyc[q] = plm2<15>(from_lane_below(pn[q]), pn[q], from_lane_above(pn[q]));
+                pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
+            }
+            __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
+            if (upd && store_lane) {
+                const long c = (long)(r - 2) * si + (long)J * sj;
+                pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2]; pwr[c + 3] = out[3];
+            }
+        }
     }
     if (WS) {
         amax = wave_max_nonneg(amax);

@@ -150,8 +150,17 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    auto kernel = P.want_wavespeed ? (P.un_mode ? sf::gam_stage_kernel<true, true> : sf::gam_stage_kernel<true, false>)
-                                   : (P.un_mode ? sf::gam_stage_kernel<false, true> : sf::gam_stage_kernel<false, false>);
+    // the full-physics instantiations (see gam_stage_kernel): same arithmetic, flag tests resolved here
+    auto active = [](const sf::Mass &m) { return m.mass > 0.0 && m.sink_model >= 1 && m.sink_model <= 3; };
+    const bool full = P.alpha > 0.0 && active(P.m[0]) && active(P.m[1]) && P.buf_on && !env_int("SFHIP_GENERIC_STAGE", 0);
+    using Kernel = void (*)(sf::GamParams, const double *, const double *, double *, double *, int, int);
+    static const Kernel table[2][2][2] = {
+        {{sf::gam_stage_kernel<false, false, false>, sf::gam_stage_kernel<false, false, true>},
+         {sf::gam_stage_kernel<false, true, false>, sf::gam_stage_kernel<false, true, true>}},
+        {{sf::gam_stage_kernel<true, false, false>, sf::gam_stage_kernel<true, false, true>},
+         {sf::gam_stage_kernel<true, true, false>, sf::gam_stage_kernel<true, true, true>}},
+    };
+    Kernel kernel = table[P.want_wavespeed ? 1 : 0][P.un_mode ? 1 : 0][full ? 1 : 0];
     hipLaunchKernelGGL(kernel, grid, block, 0, t_stream, P, prd, unsrc, pwr, wmax, nstrips, nchunks);
     return check_launch("cbdgam_2d stage launch");
 }
