@@ -295,8 +295,8 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
 }
 
 // FULL: the benchmark's physics, established on the host -- alpha viscosity on, both masses positive with
-//       active sinks, buffer on: the uniform tests on those flags drop out of the march (same arithmetic,
-//       same bits as the generic instantiation; see iso_stage_kernel).
+//       active sinks, buffer on: the uniform tests on those flags drop out of the march (same formulas,
+//       results equal to the generic instantiation's up to FMA contraction; see iso_stage_kernel).
 template <bool WS, bool UN, bool FULL>
 __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
     GamParams P, const double *__restrict__ prd, const double *unsrc,

@@ -219,8 +219,10 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 //     source terms are reused for the sound-speed estimate.
 // FULL: the benchmark's physics, established on the host -- viscosity on, locally isothermal EOS with both
 //       masses positive, buffer on.  The uniform tests on those flags (and the selects and zero defaults the
-//       untaken sides need) drop out of the march; every floating-point operation is unchanged, so FULL and
-//       generic instantiations give the same bits.
+//       untaken sides need) drop out of the march.  The formulas are unchanged; the compiler contracts a few
+//       of them into FMAs differently, so FULL and generic runs agree to the last places, not bit for bit
+//       (tests/test_hip_solver.py::test_full_physics_instantiation).  One run uses one instantiation
+//       throughout, on every patch and rank.
 template <int WS, bool UN, bool FULL>
 __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,

@@ -112,7 +112,7 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
         same = memcmp(&P.m[k].x, &P.mw[k].x, sizeof(double)) == 0 && memcmp(&P.m[k].y, &P.mw[k].y, sizeof(double)) == 0 &&
                memcmp(&P.m[k].mass, &P.mw[k].mass, sizeof(double)) == 0 &&
                memcmp(&P.m[k].rsoft, &P.mw[k].rsoft, sizeof(double)) == 0;
-    // the full-physics instantiations (see iso_stage_kernel): same arithmetic, flag tests resolved here
+    // the full-physics instantiations (see iso_stage_kernel): same formulas, flag tests resolved here
     const bool full = P.nu > 0.0 && P.eos_local && P.m[0].mass > 0.0 && P.m[1].mass > 0.0 && P.buf_on &&
                       !env_int("SFHIP_GENERIC_STAGE", 0);
     const int ws = !P.want_wavespeed ? 0 : (same ? 2 : 1);
@@ -150,7 +150,7 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    // the full-physics instantiations (see gam_stage_kernel): same arithmetic, flag tests resolved here
+    // the full-physics instantiations (see gam_stage_kernel): same formulas, flag tests resolved here
     auto active = [](const sf::Mass &m) { return m.mass > 0.0 && m.sink_model >= 1 && m.sink_model <= 3; };
     const bool full = P.alpha > 0.0 && active(P.m[0]) && active(P.m[1]) && P.buf_on && !env_int("SFHIP_GENERIC_STAGE", 0);
     using Kernel = void (*)(sf::GamParams, const double *, const double *, double *, double *, int, int);

@@ -152,3 +152,23 @@ def test_step_redoes_stage_when_filtered_wavespeed_is_below_floor():
     b.advance(dt_b)
     assert dt_a == dt_b and a.time == b.time
     assert np.array_equal(a.solution, b.solution)
+
+
+@pytest.mark.parametrize("eos", ["isothermal", "gamma-law"])
+def test_full_physics_instantiation(eos, monkeypatch):
+    """The full-physics instantiations of the stage kernels (flag tests resolved on the host)
+    evaluate the generic instantiations' formulas; the compiler contracts a few of them into FMAs
+    differently, so the trajectories agree to the last places, not bit for bit (SFHIP_GENERIC_STAGE=1
+    forces the generic ones; the variable is read at every launch).  All patches and ranks of a run use
+    the same instantiation, so decomposition invariance (test_hip_reductions) is not affected."""
+    setup = make_setup("circumbinary-disk", eos=eos)
+    mesh = setup.mesh(192)
+    runs = []
+    for generic in ("0", "1"):
+        monkeypatch.setenv("SFHIP_GENERIC_STAGE", generic)
+        s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=3, mode="hip")
+        dts = [s.step(s.recommended_cfl) for _ in range(6)]
+        runs.append((dts, s.solution))
+    assert runs[0][0][0] == runs[1][0][0]  # same initial state: bit-exact dt
+    assert max(abs(a - b) / b for a, b in zip(*[r[0] for r in runs])) <= 1e-13
+    assert zone_err(runs[0][1], runs[1][1]) <= 1e-13
