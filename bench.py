@@ -118,7 +118,7 @@ def cpu_baseline(setup_name, setup_kwargs, resolution, target_seconds):
     t0 = time.perf_counter()
     step()
     one = time.perf_counter() - t0
-    n = max(2, min(30, int(target_seconds / max(one, 1e-3))))
+    n = max(2, min(80, int(target_seconds / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
