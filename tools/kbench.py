@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--patches", type=int, default=1,
                     help="cut the mesh into this many slab patches (all on this GPU) and time patch 0: the launch "
                          "shape one rank of a multi-GPU run sees")
+    ap.add_argument("--sustained", type=int, default=0,
+                    help="also time N back-to-back launches of each variant without host synchronisation in "
+                         "between (the clocks the bench sees) and an alternation of the two RK2 stage variants")
     args = ap.parse_args()
 
     import torch
@@ -70,6 +73,24 @@ def main():
         ms = sum(times) / len(times)
         print(f"{args.solver} {ni}x{nj} {name}: {ms:.4f} ms  min {min(times):.4f}  "
               f"{zones * bytes_per_zone / (ms * 1e-3) / 1e9:7.1f} GB/s algorithmic", flush=True)
+
+    if args.sustained:
+        def burst(seq, label):
+            fires = [p.launch_stage(a, dt, p.primitive1, un, scratch, masses, masses, 0, ni, ws, floor, defer=True)
+                     for (_, a, un, ws, _) in seq]
+            for _ in range(2):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.sustained):
+                    for fire in fires:
+                        fire()
+                e1.record()
+                e1.synchronize()
+            print(f"sustained {label}: {e0.elapsed_time(e1) / args.sustained:.4f} ms per round of {len(seq)} launch(es)", flush=True)
+        burst([variants[0]], "a=0 no wavespeed")
+        burst([variants[2]], "a=1/2 u^n wavespeed")
+        burst([variants[0], variants[2]], "RK2 pair")
 
 
 if __name__ == "__main__":
