@@ -172,3 +172,19 @@ def test_full_physics_instantiation(eos, monkeypatch):
     assert runs[0][0][0] == runs[1][0][0]  # same initial state: bit-exact dt
     assert max(abs(a - b) / b for a, b in zip(*[r[0] for r in runs])) <= 1e-13
     assert zone_err(runs[0][1], runs[1][1]) <= 1e-13
+
+
+def test_gam_decomposition_invariance_2048():
+    """cbdgam_2d at a size with many row chunks per patch (chunk boundaries fall on different rows in the
+    1-patch and 8-patch runs; 8 x 256 rows is the per-GPU shape of BASELINE configs[3] scaled down): slab
+    decomposition changes neither dt nor a single bit of the state."""
+    setup = make_setup("circumbinary-disk", eos="gamma-law")
+    mesh = setup.mesh(2048)
+    runs = []
+    for num_patches in (1, 8):
+        s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=num_patches,
+                        mode="hip")
+        dts = [s.step(s.recommended_cfl) for _ in range(3)]
+        runs.append((dts, s.solution))
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
