@@ -56,6 +56,9 @@ def main():
         ("a=1/2 u^n,    wavespeed   ", 0.5, p.primitive2, 2, 3 * 8 * ncons),
         ("a=0   no u^n, wavespeed   ", 0.0, None, 2, 2 * 8 * ncons),
         ("a=0   no u^n, no wavespeed", 0.0, None, 0, 2 * 8 * ncons),  # again: the first line warms the clocks
+        # u^n read from the array the stencil reads (rows a wave loaded three iterations earlier: cache hits).
+        # Same instructions as the u^n variant without its HBM traffic: what that traffic costs.
+        ("a=1/2 u^n = rd (cached)     ", 0.5, p.primitive1, 0, 2 * 8 * ncons),
     ]
     scratch = torch.empty_like(p.primitive1)
     for name, a, un, ws, bytes_per_zone in variants:
