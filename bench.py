@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC: RCCL between processes needs this (already exported
+# on the boxes; kept here so that the multi-rank launch does not depend on the caller's environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
