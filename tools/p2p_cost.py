@@ -41,7 +41,32 @@ def main():
                 r.wait()
         torch.cuda.current_stream().wait_stream(comm)
 
+    slabs = torch.zeros(2 * n, dtype=torch.float64, device="cuda")
+    gathered = torch.zeros(2 * n * dist.get_world_size(), dtype=torch.float64, device="cuda")
+
+    def gather():  # the alternative transport: every rank's two boundary slabs in one collective
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            dist.all_gather_into_tensor(gathered, slabs)
+        torch.cuda.current_stream().wait_stream(comm)
+
+    ready, done = torch.cuda.Event(), torch.cuda.Event()
+
+    def exchange_cached_events():  # same exchange with two events created once instead of wait_stream's per call
+        ops = [dist.P2POp(dist.isend, a[0], 0), dist.P2POp(dist.irecv, a[1], 0),
+               dist.P2POp(dist.isend, a[2], 0), dist.P2POp(dist.irecv, a[3], 0)]
+        ready.record()
+        comm.wait_event(ready)
+        with torch.cuda.stream(comm):
+            reqs = dist.batch_isend_irecv(ops)
+            for r in reqs:
+                r.wait()
+            done.record()
+        torch.cuda.current_stream().wait_event(done)
+
     for name, fn in (("halo exchange (2 send + 2 recv)", exchange),
+                     ("same, events created once", exchange_cached_events),
+                     ("all_gather_into_tensor of 2 slabs", gather),
                      ("all_reduce MAX of one double", lambda: dist.all_reduce(amax, op=dist.ReduceOp.MAX))):
         for _ in range(10):
             fn()
