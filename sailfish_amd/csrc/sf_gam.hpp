@@ -76,8 +76,12 @@ __device__ __forceinline__ void gam_p2c(const double *p, double *u, double gamma
 }
 
 // One point mass, cbdgam_2d.c:108-203, IEEE arithmetic (diagnostics kernel).  Adds its contribution to u.
+// `us`: where the sink's contributions go (the diagnostics keep gravity and accretion apart); `u` when null.
+// With the two apart, each part has exactly the value the reference's gravity-only (sink_rate * 0) and
+// accretion-only (mass * 0) calls give it: the other part's terms are exact zeros there.
 __device__ __forceinline__ void gam_mass_source(const Mass &m, double x1, double y1, double dt, const double *prim,
-                                                double h, double *u, int constant_softening, double gamma)
+                                                double h, double *u, int constant_softening, double gamma,
+                                                double *us = nullptr)
 {
     double sigma = prim[0];
     double eps = prim[3] / sigma / (gamma - 1.0);
@@ -109,6 +113,28 @@ __device__ __forceinline__ void gam_mass_source(const Mass &m, double x1, double
     double fy = -fnum * ddy;
     double mdot = sigma * rate * -1.0;
     double vx = prim[1], vy = prim[2];
+    if (us) {
+        if (m.sink_model < 1 || m.sink_model > 3) return;
+        u[1] += dt * fx;
+        u[2] += dt * fy;
+        u[3] += dt * (fx * vx + fy * vy);
+        us[0] += dt * mdot;
+        if (m.sink_model == 1) {
+            us[1] += dt * mdot * vx;
+            us[2] += dt * mdot * vy;
+            us[3] += dt * (mdot * eps + 0.5 * mdot * (vx * vx + vy * vy));
+        } else if (m.sink_model == 2) {
+            double rhx = ddx / (dr + 1e-12);
+            double rhy = ddy / (dr + 1e-12);
+            double dv = (vx - m.vx) * rhx + (vy - m.vy) * rhy;
+            double vxs = dv * rhx + m.vx;
+            double vys = dv * rhy + m.vy;
+            us[1] += dt * mdot * vxs;
+            us[2] += dt * mdot * vys;
+            us[3] += dt * (mdot * eps + 0.5 * mdot * (vxs * vxs + vys * vys));
+        }
+        return;
+    }
     if (m.sink_model == 1) {
         u[0] += dt * mdot;
         u[1] += dt * mdot * vx + dt * fx;

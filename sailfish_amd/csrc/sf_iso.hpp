@@ -133,11 +133,13 @@ __device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, dou
 // `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed; `sink_reach2` =
 // (4 r_sink)^2 + rs^2.  `cold` points at the same mass in memory: what only the sink branch needs
 // (a handful of waves per launch) is loaded there, on demand, instead of occupying SGPRs throughout.
+// `ds`: where the sink's contributions go (the diagnostics keep gravity and accretion apart); `dc` when null.
 __device__ __forceinline__ double iso_mass_source(double mx, double mmass, double sink_reach2, const Mass *cold,
                                                   double x1, double ddy, double cy, double dt,
-                                                  const double *prim, double *dc)
+                                                  const double *prim, double *dc, double *ds = nullptr)
 {
 #pragma clang fp contract(fast)
+    if (!ds) ds = dc;
     double sigma = prim[0];
     double ddx = x1 - mx;
     double r2s = ddx * ddx + cy;
@@ -160,9 +162,9 @@ __device__ __forceinline__ double iso_mass_source(double mx, double mmass, doubl
             if (rate > 0.0) mdot = -rate * sigma;
             else if (rate < 0.0) mdot = -rate;
             if (sink_model == 1) {
-                dc[0] += dt * mdot;
-                dc[1] += dt * mdot * prim[1];
-                dc[2] += dt * mdot * prim[2];
+                ds[0] += dt * mdot;
+                ds[1] += dt * mdot * prim[1];
+                ds[2] += dt * mdot * prim[2];
             } else if (sink_model == 2) {
                 double rinv = 1.0 / (dr + 1e-12);
                 double rhx = ddx * rinv;
@@ -170,11 +172,11 @@ __device__ __forceinline__ double iso_mass_source(double mx, double mmass, doubl
                 double dv = (prim[1] - mvx) * rhx + (prim[2] - mvy) * rhy;
                 double vxs = dv * rhx + mvx;
                 double vys = dv * rhy + mvy;
-                dc[0] += dt * mdot;
-                dc[1] += dt * mdot * vxs;
-                dc[2] += dt * mdot * vys;
+                ds[0] += dt * mdot;
+                ds[1] += dt * mdot * vxs;
+                ds[2] += dt * mdot * vys;
             } else if (sink_model == 3) {
-                dc[0] += dt * mdot;
+                ds[0] += dt * mdot;
             }
         }
     }
@@ -183,10 +185,10 @@ __device__ __forceinline__ double iso_mass_source(double mx, double mmass, doubl
 
 // convenience form for the small kernels (everything from the by-value struct)
 __device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double ddy, double cy, double dt,
-                                                const double *prim, double *dc)
+                                                const double *prim, double *dc, double *ds = nullptr)
 {
     double rs4 = 4.0 * m.sink_radius;
-    iso_mass_source(m.x, m.mass, rs4 * rs4 + m.rsoft * m.rsoft, &m, x1, ddy, cy, dt, prim, dc);
+    iso_mass_source(m.x, m.mass, rs4 * rs4 + m.rsoft * m.rsoft, &m, x1, ddy, cy, dt, prim, dc, ds);
 }
 
 // Keplerian buffer, cbdiso_2d.c:213-246

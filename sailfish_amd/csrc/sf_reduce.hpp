@@ -36,34 +36,36 @@ enum {
 struct ReduceParams {
     int ni, nj;
     double xl, yl, dx, dy;
-    Mass mg[2];   // masses with sink_rate = 0 (gravity = True, accretion = False)
-    Mass ma[2];   // masses with mass = 0 (accretion = True, gravity = False)
+    // The reference evaluates the source-term kernel four times: per mass with sink_rate * 0 (gravity = True,
+    // accretion = False) and with mass * 0 (accretion = True, gravity = False).  In either call the other
+    // part's terms are exact zeros, so one evaluation per mass that keeps the two parts in separate
+    // accumulators gives both calls' values (up to the sign of a zero) for half the arithmetic.
+    Mass m[2];
     double v[2][2]; // velocities of the two masses (for "power")
     double gamma;
     int constant_softening;
 };
 
+// gravity (rg) and accretion (ra) rates of the conserved fields from the two masses
 template <int NQ>
 __device__ __forceinline__ void zone_rates(const ReduceParams &P, const Mass *m, double xc, double yc,
-                                           const double *p, double (*rate)[NQ])
+                                           const double *p, double (*rg)[NQ], double (*ra)[NQ])
 {
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { rg[w][q] = 0.0; ra[w][q] = 0.0; }
     if (NQ == 3) {
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-            double dc[3] = {0.0, 0.0, 0.0};
             double ddy = yc - m[w].y;
-            iso_mass_source(m[w], xc, ddy, ddy * ddy + m[w].rsoft * m[w].rsoft, 1.0, p, dc);
-            rate[w][0] = dc[0]; rate[w][1] = dc[1]; rate[w][2] = dc[2];
+            iso_mass_source(m[w], xc, ddy, ddy * ddy + m[w].rsoft * m[w].rsoft, 1.0, p, rg[w], ra[w]);
         }
     } else {
         double h = gam_height(sqrt(p[3] / p[0]), gam_omega2(m, xc, yc));
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            double dc[4] = {0.0, 0.0, 0.0, 0.0};
-            gam_mass_source(m[w], xc, yc, 1.0, p, h, dc, P.constant_softening, P.gamma);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) rate[w][q] = dc[q];
-        }
+        for (int w = 0; w < 2; ++w)
+            gam_mass_source(m[w], xc, yc, 1.0, p, h, rg[w], P.constant_softening, P.gamma, ra[w]);
     }
 }
 
@@ -91,8 +93,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams P, const doubl
 #pragma unroll
             for (int q = 0; q < NQ; ++q) p[q] = prim[n + q];
             double rg[2][NQ], ra[2][NQ];
-            zone_rates<NQ>(P, P.mg, xc, yc, p, rg);
-            zone_rates<NQ>(P, P.ma, xc, yc, p, ra);
+            zone_rates<NQ>(P, P.m, xc, yc, p, rg, ra);
             const double r = sqrt(x * x + y * y);
 #pragma unroll
             for (int d = 0; d < RED_MAXD; ++d) {

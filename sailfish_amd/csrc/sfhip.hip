@@ -624,12 +624,7 @@ static int reductions_impl(const char *name, int ni, int nj, double pxl, double 
     P.xl = pxl; P.yl = pyl;
     P.dx = (pxr - pxl) / ni;
     P.dy = (pyr - pyl) / nj;
-    P.mg[0] = m1; P.mg[1] = m2;
-    P.ma[0] = m1; P.ma[1] = m2;
-    for (int w = 0; w < 2; ++w) {
-        P.mg[w].sink_rate = P.mg[w].sink_rate * 0.0; // sink_rate * accretion with accretion = False
-        P.ma[w].mass = P.ma[w].mass * 0.0;           // mass * gravity with gravity = False
-    }
+    P.m[0] = m1; P.m[1] = m2;
     P.v[0][0] = m1.vx; P.v[0][1] = m1.vy;
     P.v[1][0] = m2.vx; P.v[1][1] = m2.vy;
     P.gamma = gamma;
