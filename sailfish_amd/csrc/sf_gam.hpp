@@ -588,12 +588,28 @@ __global__ void gam_wavespeed_kernel(int ni, int nj, double gamma, const double 
     double a = 0.0;
     if (j < nj) {
         const long NJ = nj + 2 * NG;
-        for (long i = blockIdx.y; i < ni; i += gridDim.y) {
-            long z = (i + NG) * NJ + (j + NG);
-            double c2 = prim[z * 4 + 3] / prim[z * 4] * gamma;
-            double s = max_speed(prim[z * 4 + 1], prim[z * 4 + 2], c2);
-            if (out) out[z] = s;
-            a = max2(a, s);
+        // four rows per trip, their loads issued together (see iso_wavespeed_kernel)
+        constexpr int U = 4;
+        for (long i0 = (long)blockIdx.y * U; i0 < ni; i0 += (long)gridDim.y * U) {
+            double p[U][4];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long i = i0 + k < ni ? i0 + k : ni - 1;
+                const long z = (i + NG) * NJ + (j + NG);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p[k][q] = prim[z * 4 + q];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long i = i0 + k;
+                if (i < ni) {
+                    const long z = (i + NG) * NJ + (j + NG);
+                    double c2 = p[k][3] / p[k][0] * gamma;
+                    double s = max_speed(p[k][1], p[k][2], c2);
+                    if (out) out[z] = s;
+                    a = max2(a, s);
+                }
+            }
         }
     }
     if (wmax) {

@@ -499,13 +499,29 @@ __global__ void iso_wavespeed_kernel(IsoParams P, const double *__restrict__ pri
     if (j < P.nj) {
         const long NJ = P.nj + 2 * NG;
         const double y = P.yl + (j + 0.5) * P.dy;
-        for (long i = blockIdx.y; i < P.ni; i += gridDim.y) {
-            long z = (i + NG) * NJ + (j + NG);
-            double x = P.xl + (i + 0.5) * P.dx;
-            double c2 = iso_cs2(P, P.m, x, y);
-            double s = max_speed(prim[z * 3 + 1], prim[z * 3 + 2], c2);
-            if (out) out[z] = s;
-            a = max2(a, s);
+        // four rows per trip, their loads issued together: with one row per trip the kernel was bound by the
+        // latency of its single outstanding load per lane (0.39 ms at 4096^2 for 0.54 GB)
+        constexpr int U = 4;
+        for (long i0 = (long)blockIdx.y * U; i0 < P.ni; i0 += (long)gridDim.y * U) {
+            double vx[U], vy[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long i = i0 + k < P.ni ? i0 + k : P.ni - 1;
+                const long z = (i + NG) * NJ + (j + NG);
+                vx[k] = prim[z * 3 + 1]; vy[k] = prim[z * 3 + 2];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long i = i0 + k;
+                if (i < P.ni) {
+                    const long z = (i + NG) * NJ + (j + NG);
+                    double x = P.xl + (i + 0.5) * P.dx;
+                    double c2 = iso_cs2(P, P.m, x, y);
+                    double s = max_speed(vx[k], vy[k], c2);
+                    if (out) out[z] = s;
+                    a = max2(a, s);
+                }
+            }
         }
     }
     if (wmax) {
