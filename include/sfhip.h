@@ -549,6 +549,10 @@ SFHIP_API int sfhip_reductions_workspace_len(
  * srhd_2d -- 2-D special-relativistic hydrodynamics on a log-spherical, homologously
  * expanding mesh (BASELINE.json configs[4]).
  * State arrays are (ni + 4, nj, 4): two guard zones in i only, fields fastest.
+ * Allocation / synchronisation: the first call on a device, and the first call for a new
+ * (nj, polar_extent), builds a table of sin/cos of the polar face angles on the host (libm,
+ * for bit-identical zone volumes) and uploads it with a blocking copy; tables live until the
+ * process ends (at most 32 meshes per device).  Every later call is an asynchronous launch.
  * --------------------------------------------------------------------------- */
 
 /* The reference compiles PLM_THETA and MACH_CEILING into the kernel library

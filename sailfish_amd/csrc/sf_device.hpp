@@ -217,19 +217,21 @@ __device__ __forceinline__ double exp_cold(double x)
     return ldexp(p, (int)n);
 }
 
-// max of a non-negative double over the wave, result valid in every lane
+// The wavespeed folds keep a NaN from either side, as numpy's max does, which is what the reference applies to
+// its per-zone wavespeed array (cbdiso_2d.py:174): a blown-up state must give a NaN dt, not a finite one.
+__device__ __forceinline__ double max_nan(double a, double s) { return (s > a || s != s) ? s : a; }
+
+// max of a non-negative double over the wave, result valid in every lane (NaN if any lane holds one)
 __device__ __forceinline__ double wave_max_nonneg(double v)
 {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
+    for (int off = 32; off >= 1; off >>= 1) v = max_nan(v, __shfl_xor(v, off, 64));
     return v;
 }
 
 // Non-negative doubles order like their bit patterns, so a 64-bit integer
-// atomic max implements the floating-point max exactly (bit-exact dt).
+// atomic max implements the floating-point max exactly (bit-exact dt); a NaN's
+// pattern ranks above every finite value and infinity, so it survives too.
 __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
 {
     atomicMax(reinterpret_cast<unsigned long long *>(addr),

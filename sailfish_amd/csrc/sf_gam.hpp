@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                 }
                 // cbdgam_2d.c:319-345
                 double rinv = fast_rcp(u[0]);
-                double pres = __builtin_fmax(P.pfloor, (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) * rinv) * P.gm1);
+                // max2(pressure_floor, .) of the reference: a NaN energy stays a NaN pressure (fmax would floor it)
+                double pres = (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) * rinv) * P.gm1;
+                pres = pres < P.pfloor ? P.pfloor : pres;
                 double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
                 double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
                 double rho = u[0];
@@ -538,8 +540,8 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                         // get the IEEE evaluation, so the reduced maximum is bit-exact
                         double pre = pres * fast_rcp(rho) * gamma;
                         double cse = sqrt_from_rsqrt(pre, fast_rsqrt(pre));
-                        if ((__builtin_fmax(fabs(vx), fabs(vy)) + cse) * (1.0 + 1e-9) >= athr) {
-                            amax = max2(amax, gam_exact_speed(vx, vy, pres, rho, gamma));
+                        if (!((max2(fabs(vx), fabs(vy)) + cse) * (1.0 + 1e-9) < athr)) { // unordered passes
+                            amax = max_nan(amax, gam_exact_speed(vx, vy, pres, rho, gamma));
                             athr = max2(athr, amax);
                         }
                     }
@@ -607,7 +609,7 @@ __global__ void gam_wavespeed_kernel(int ni, int nj, double gamma, const double 
                     double c2 = p[k][3] / p[k][0] * gamma;
                     double s = max_speed(p[k][1], p[k][2], c2);
                     if (out) out[z] = s;
-                    a = max2(a, s);
+                    a = max_nan(a, s);
                 }
             }
         }

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                     // fl(max(|vx|,|vy|) + cs).  A ~1-ulp estimate of cs filters the zones that
                     // cannot raise this lane's running maximum; the rest take the IEEE path,
                     // so the reduced value is bit-identical to cbdiso_2d_wavespeed + max.
-                    double vm = __builtin_fmax(fabs(vx), fabs(vy));
+                    // (`?:` as the reference's max2: the zone's speed is NaN when vy or cs is, not when only vx is)
+                    double vm = max2(fabs(vx), fabs(vy));
                     double c2e, cse;
                     if (WS == 2) {
                         if (!FULL && !P.eos_local) cse = P.cs_uniform;
@@ -446,9 +447,9 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                     } else {
                         iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
                     }
-                    if ((vm + cse) * (1.0 + 1e-9) >= athr) {
+                    if (!((vm + cse) * (1.0 + 1e-9) < athr)) { // unordered passes: a NaN must reach the fold
                         double sp = iso_exact_speed(Pk, xc, yc, vx, vy);
-                        amax = max2(amax, sp);
+                        amax = max_nan(amax, sp);
                         athr = max2(athr, amax);
                     }
                 }
@@ -519,7 +520,7 @@ __global__ void iso_wavespeed_kernel(IsoParams P, const double *__restrict__ pri
                     double c2 = iso_cs2(P, P.m, x, y);
                     double s = max_speed(vx[k], vy[k], c2);
                     if (out) out[z] = s;
-                    a = max2(a, s);
+                    a = max_nan(a, s);
                 }
             }
         }

@@ -4,8 +4,10 @@
 //
 // Conventions
 //   * every pointer is a DEVICE pointer on the current device;
-//   * launches go to the calling thread's current stream (sfhip_set_stream),
-//     nothing here synchronises or allocates;
+//   * launches go to the calling thread's current stream (sfhip_set_stream); nothing here
+//     synchronises or allocates, with two exceptions: the first srhd_2d call on a device or
+//     for a new (nj, polar_extent) builds a small table (see srhd_state), and
+//     sfhip_srhd_2d_failures reads a counter back;
 //   * entry points return 0 on success, a hipError_t value (or -1 for argument
 //     errors) otherwise; sfhip_last_error() describes the last failure.
 #include <hip/hip_runtime.h>
@@ -13,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "sf_dg.hpp"
 #include "sf_gam.hpp"
@@ -254,7 +257,7 @@ __global__ void max_nonneg_kernel(const double *__restrict__ x, long n, double *
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = k + u * stride < n ? x[k + u * stride] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a = v[u] > a ? v[u] : a;
+        for (int u = 0; u < 8; ++u) a = sf::max_nan(a, v[u]);
     }
     // one atomic per block: thousands of same-address atomics at the end of so short a kernel serialise
     __shared__ double wave_max[4];
@@ -263,7 +266,7 @@ __global__ void max_nonneg_kernel(const double *__restrict__ x, long n, double *
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = wave_max[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = wave_max[w] > m ? wave_max[w] : m;
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = sf::max_nan(m, wave_max[w]);
         sf::atomic_max_nonneg(out, m);
     }
 }
@@ -696,63 +699,78 @@ int sfhip_cbdgam_2d_reductions(
 namespace {
 
 constexpr int SR_MAX_DEVICES = 64;
+constexpr int SR_MAX_TABLES = 32;
 thread_local double t_sr_theta = 1.5;         // srhd_2d.py:66 (Options.plm_theta)
 thread_local double t_sr_mach_ceiling = 1e6;  // srhd_2d.py:67
 
-// Per-device state of the srhd entry points, created on first use (the one place this library
-// allocates): the polar trigonometry table, filled on the host with libm so that zone volumes and
-// face areas carry exactly the reference's bits, and the conserved_to_primitive failure counter.
+// Per-device state of the srhd entry points.  The first call for a (device, nj, polar_extent) allocates
+// and fills a polar trigonometry table -- on the host with libm, so that zone volumes and face areas carry
+// exactly the reference's bits -- and the first call on a device allocates the conserved_to_primitive failure
+// counter; those first calls block (hipMalloc, synchronous copy).  Tables are kept until the process ends
+// (a solver per mesh, a handful of meshes per process), so steady-state calls neither allocate nor
+// synchronise, and two solvers with different meshes do not evict each other.  The cache is guarded by a
+// mutex; the stream and error buffer are per thread.
+struct SrhdTable {
+    int nj;
+    double polar_extent;
+    double *trig; // sin(dq j), j = 0..nj, then cos(dq j), j = 0..nj
+};
 struct SrhdDeviceState {
-    int nj = -1;
-    double polar_extent = 0.0;
-    double *trig = nullptr;        // sin(dq j), j = 0..nj, then cos(dq j), j = 0..nj
     unsigned int *failures = nullptr;
+    int ntables = 0;
+    SrhdTable tables[SR_MAX_TABLES];
 };
 SrhdDeviceState g_sr[SR_MAX_DEVICES];
+std::mutex g_sr_mutex;
 
-int srhd_state(int nj, double polar_extent, SrhdDeviceState **out)
+int srhd_state(int nj, double polar_extent, SrhdDeviceState **out, const double **trig)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     if (dev < 0 || dev >= SR_MAX_DEVICES) return fail(-1, "srhd_2d: device index out of range");
+    std::lock_guard<std::mutex> lock(g_sr_mutex);
     SrhdDeviceState &st = g_sr[dev];
     if (!st.failures) {
         e = hipMalloc((void **)&st.failures, sizeof(unsigned int));
         if (e == hipSuccess) e = hipMemset(st.failures, 0, sizeof(unsigned int));
-        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    }
-    if (st.nj != nj || memcmp(&st.polar_extent, &polar_extent, sizeof(double)) != 0) {
-        if (st.trig) {
-            (void)hipDeviceSynchronize(); // kernels of an earlier mesh may still be reading the old table
-            (void)hipFree(st.trig);
-            st.trig = nullptr;
-            st.nj = -1;
-        }
-        const size_t n = (size_t)nj + 1;
-        double *host = (double *)malloc(2 * n * sizeof(double));
-        if (!host) return fail(-1, "srhd_2d: out of host memory");
-        const double dq = polar_extent / nj; // srhd_2d.c:524
-        for (size_t j = 0; j < n; ++j) {
-            const double q = dq * (double)j; // dq * (j + 0) and dq * (j + 1) of the reference
-            host[j] = sin(q);
-            host[n + j] = cos(q);
-        }
-        e = hipMalloc((void **)&st.trig, 2 * n * sizeof(double));
-        if (e == hipSuccess) e = hipMemcpy(st.trig, host, 2 * n * sizeof(double), hipMemcpyHostToDevice);
-        free(host);
-        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-        st.nj = nj;
-        st.polar_extent = polar_extent;
+        if (e != hipSuccess) { st.failures = nullptr; return fail((int)e, hipGetErrorString(e)); }
     }
     *out = &st;
+    for (int k = 0; k < st.ntables; ++k) {
+        if (st.tables[k].nj == nj && memcmp(&st.tables[k].polar_extent, &polar_extent, sizeof(double)) == 0) {
+            *trig = st.tables[k].trig;
+            return 0;
+        }
+    }
+    if (st.ntables == SR_MAX_TABLES) return fail(-1, "srhd_2d: too many distinct (nj, polar_extent) meshes in one process");
+    const size_t n = (size_t)nj + 1;
+    double *host = (double *)malloc(2 * n * sizeof(double));
+    if (!host) return fail(-1, "srhd_2d: out of host memory");
+    const double dq = polar_extent / nj; // srhd_2d.c:524
+    for (size_t j = 0; j < n; ++j) {
+        const double q = dq * (double)j; // dq * (j + 0) and dq * (j + 1) of the reference
+        host[j] = sin(q);
+        host[n + j] = cos(q);
+    }
+    double *table = nullptr;
+    e = hipMalloc((void **)&table, 2 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(table, host, 2 * n * sizeof(double), hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess) {
+        if (table) (void)hipFree(table);
+        return fail((int)e, hipGetErrorString(e));
+    }
+    st.tables[st.ntables++] = SrhdTable{nj, polar_extent, table};
+    *trig = table;
     return 0;
 }
 
 int srhd_fill(sf::SrhdParams &P, int ni, int nj, const double *faces, double polar_extent, SrhdDeviceState **st)
 {
     if (ni < 1 || nj < 1 || !faces) return fail(-1, "srhd_2d: bad shape or null face_positions");
-    int rc = srhd_state(nj, polar_extent, st);
+    const double *trig = nullptr;
+    int rc = srhd_state(nj, polar_extent, st, &trig);
     if (rc) return rc;
     memset(&P, 0, sizeof(P));
     P.ni = ni; P.nj = nj;
@@ -761,8 +779,8 @@ int srhd_fill(sf::SrhdParams &P, int ni, int nj, const double *faces, double pol
     P.theta = t_sr_theta;
     P.mach_ceiling2 = pow(t_sr_mach_ceiling, 2.0); // srhd_2d.c:156, host libm as in the reference
     P.faces = faces;
-    P.sinq = (*st)->trig;
-    P.cosq = (*st)->trig + (nj + 1);
+    P.sinq = trig;
+    P.cosq = trig + (nj + 1);
     return 0;
 }
 

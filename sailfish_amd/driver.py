@@ -56,6 +56,11 @@ def simulate(solver, mesh, cfl_number=None, fold=10, new_timestep_cadence=1, max
                     solver.advance(dt)
                 iteration += 1
         seconds = fold_time()
+        # srhd_2d: where the reference's C path prints [FATAL] and exits from inside the kernel
+        # (srhd_2d.c:164-184) the device counts the zone; surface that once per fold, outside the timed
+        # region (one 4-byte read-back), instead of carrying on with garbage primitives
+        if hasattr(solver, "check_failures"):
+            solver.check_failures()
         mzps = mesh.num_total_zones / seconds * 1e-6 * steps
         yield FoldReport(iteration, solver.time, dt, mzps, seconds)
 

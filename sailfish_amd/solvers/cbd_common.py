@@ -69,11 +69,15 @@ class HipBackend:
         return num_devices("hip")
 
 
+_UNSET = object()
+
+
 class Comm:
     """Thin view of torch.distributed: who am I, and the few collectives the solver needs."""
 
     def __init__(self, enabled):
         self.enabled = enabled
+        self._host_group = _UNSET
         if enabled:
             import torch.distributed as dist
 
@@ -102,13 +106,60 @@ class Comm:
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.MAX)
         return tensor
 
-    def gather_arrays(self, local):
-        """All ranks receive the list of every rank's numpy array (checkpoint path only)."""
+    def host_group(self):
+        """
+        The process group host arrays travel on: the default group when it is gloo, else a gloo group beside
+        the RCCL one (created on first use; every rank reaches that point together, inside a collective
+        gather).  Checkpoint gathers and the diagnostics' per-patch sums are host data: moving them through
+        RCCL would stage them in device memory next to the solver state.
+        """
+        if self._host_group is _UNSET:
+            self._host_group = None if self.dist.get_backend() == "gloo" else self.dist.new_group(backend="gloo")
+        return self._host_group
+
+    def gather_arrays(self, local, root=0):
+        """
+        Rank `root` receives the list of every rank's float64 array (in rank order) and the other ranks, which
+        only send theirs, get None: one copy of the mesh on one host, as the reference's concat_on_host makes
+        (subdivide.py:63-122).  Arrays travel as raw doubles (no pickling); shapes may differ between ranks.
+        """
         if not self.enabled:
             return [local]
-        out = [None] * self.size
-        self.dist.all_gather_object(out, local)
-        return out
+        import torch
+
+        dist, group = self.dist, self.host_group()
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        meta = torch.zeros(8, dtype=torch.int64)
+        meta[0] = local.ndim
+        meta[1:1 + local.ndim] = torch.tensor(local.shape, dtype=torch.int64)
+        metas = [torch.zeros(8, dtype=torch.int64) for _ in range(self.size)]
+        dist.all_gather(metas, meta, group=group)
+        if self.rank != root:
+            dist.send(torch.from_numpy(local), dst=root, group=group)
+            return None
+        parts, requests = [], []
+        for r in range(self.size):
+            if r == root:
+                parts.append(local)
+                continue
+            shape = tuple(int(v) for v in metas[r][1:1 + int(metas[r][0])])
+            buf = torch.empty(shape, dtype=torch.float64)
+            requests.append(dist.irecv(buf, src=r, group=group))
+            parts.append(buf.numpy())
+        for req in requests:
+            req.wait()
+        return parts
+
+    def all_gather_arrays(self, local):
+        """Every rank receives the list of every rank's array; for SMALL arrays of one shape (per-patch sums)."""
+        if not self.enabled:
+            return [local]
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+        out = [torch.zeros_like(t) for _ in range(self.size)]
+        self.dist.all_gather(out, t, group=self.host_group())
+        return [o.numpy() for o in out]
 
 
 class PatchBase:
@@ -305,9 +356,13 @@ class SolverBase:
     # ------------------------------------------------------------------ state
     @property
     def solution(self):
-        """(ni, nj, NCONS) float64 host array without guards (reference: cbdiso_2d.py:357-361)."""
+        """
+        (ni, nj, NCONS) float64 host array without guards (reference: cbdiso_2d.py:357-361).  In a multi-rank
+        run this is a collective call: rank 0 returns the array, the other ranks return None.
+        """
         local = concat_on_host([p.primitive for p in self.patches], (NG, NG))
-        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+        parts = self.comm.gather_arrays(local)
+        return None if parts is None else np.concatenate(parts, axis=0)
 
     @property
     def primitive(self):
@@ -368,7 +423,7 @@ class SolverBase:
             for n, sums in enumerate(pending):  # all patches launched before the first blocking read
                 per_patch[n] = to_host(sums).reshape(len(work), 2)
             del torch
-        gathered = np.concatenate(self.comm.gather_arrays(per_patch), axis=0)  # global patch order
+        gathered = np.concatenate(self.comm.all_gather_arrays(per_patch), axis=0)  # global patch order
         da = self.mesh.dx * self.mesh.dy
         result = [None] * len(diagnostics)
         for k, d in enumerate(diagnostics):

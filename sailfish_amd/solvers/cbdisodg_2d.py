@@ -365,13 +365,15 @@ class Solver(SolverBase):
     def solution(self):
         """(ni, nj, 3, 3, 3) float64 host array without guards (cbdisodg_2d.py:407-414)."""
         local = concat_on_host([p.weights1 for p in self.patches], (GUARD, GUARD), rank=2)
-        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+        parts = self.comm.gather_arrays(local)  # collective: the array on rank 0, None on the other ranks
+        return None if parts is None else np.concatenate(parts, axis=0)
 
     @property
     def primitive(self):
         """(ni, nj, 3) zone-average primitives on the host (cbdisodg_2d.py:416-423)."""
         local = concat_on_host([p.primitive for p in self.patches], (GUARD, GUARD), rank=2)
-        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+        parts = self.comm.gather_arrays(local)  # collective: the array on rank 0, None on the other ranks
+        return None if parts is None else np.concatenate(parts, axis=0)
 
     def reductions(self):
         raise NotImplementedError(

@@ -291,12 +291,14 @@ class Solver(SolverBase):
     def solution(self):
         """Conserved variables, (ni, nj, 4) host array without guards (srhd_2d.py:291-293)."""
         local = concat_on_host([p.conserved for p in self.patches], (NUM_GUARD, 0))
-        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+        parts = self.comm.gather_arrays(local)  # collective: the array on rank 0, None on the other ranks
+        return None if parts is None else np.concatenate(parts, axis=0)
 
     @property
     def primitive(self):
         local = concat_on_host([p.primitive for p in self.patches], (NUM_GUARD, 0))
-        return np.concatenate(self.comm.gather_arrays(local), axis=0)
+        parts = self.comm.gather_arrays(local)  # collective: the array on rank 0, None on the other ranks
+        return None if parts is None else np.concatenate(parts, axis=0)
 
     @property
     def recommended_cfl(self):

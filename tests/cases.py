@@ -44,7 +44,7 @@ NO_MASS = mass(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0)
 
 
 def iso_case(seed=0, ni=32, nj=48, eos=2, nu=0.001, buffer_on=True, sink_model=2, a=0.0, masses=True,
-             smooth=False, extent=(-1.6, 1.6, -2.4, 2.4), sink_rate=10.0, dt=1e-3):
+             smooth=False, extent=(-1.6, 1.6, -2.4, 2.4), sink_rate=10.0, dt=1e-3, vmax=1e12, dfloor=1e-12):
     """Keyword dict for cbdiso_2d_advance_rk (minus the three arrays) plus the input arrays."""
     prim = smooth_primitive(ni, nj, 3, extent) if smooth else random_primitive(seed, ni, nj, 3)
     cons = np.zeros_like(prim)
@@ -61,7 +61,7 @@ def iso_case(seed=0, ni=32, nj=48, eos=2, nu=0.001, buffer_on=True, sink_model=2
     return dict(
         shape=(ni, nj), extent=extent, prim=prim, cons=cons,
         buffer=(0.8, m1[4] + m2[4], 100.0, max(abs(extent[1]), abs(extent[3])), 0.5, int(buffer_on)),
-        m1=m1, m2=m2, eos=(1.3, 100.0, eos), nu=nu, a=a, dt=dt, vmax=1e12, dfloor=1e-12,
+        m1=m1, m2=m2, eos=(1.3, 100.0, eos), nu=nu, a=a, dt=dt, vmax=vmax, dfloor=dfloor,
     )
 
 
@@ -86,11 +86,25 @@ def iso_branch_matrix():
     combos.append(dict(ni=5, nj=3))                    # tiny, ragged
     combos.append(dict(ni=1, nj=1))
     combos.append(dict(ni=67, nj=131, smooth=True))    # several strips / not multiples of anything
+    # primitive recovery with its limits engaged (cbdiso_2d.c:268-283): with rho in [0.1, 2] and |v| <= 2 a
+    # density floor of 0.6 catches about a quarter of the zones and a velocity ceiling of 0.9 about half
+    combos.append(dict(dfloor=0.6))
+    combos.append(dict(vmax=0.9))
+    combos.append(dict(dfloor=0.6, vmax=0.9, a=0.5))
+    combos.append(dict(dfloor=0.6, vmax=0.9, a=0.5, eos=1, sink_model=1, ni=67, nj=131))
     return combos
 
 
+def iso_limits_engaged(c, out):
+    """(zones whose density sits on the floor, zones with a velocity component on the ceiling) in an output array."""
+    inner = out[NG:-NG, NG:-NG]
+    return (int((inner[..., 0] == c["dfloor"]).sum()),
+            int((np.abs(inner[..., 1:3]) == c["vmax"]).any(axis=-1).sum()))
+
+
 def gam_case(seed=0, ni=32, nj=48, alpha=0.1, buffer_on=True, sink_model=2, a=0.0, masses=True, smooth=False,
-             extent=(-1.6, 1.6, -2.4, 2.4), cooling=0.0, constant_softening=True, dt=1e-3, gamma=5.0 / 3.0):
+             extent=(-1.6, 1.6, -2.4, 2.4), cooling=0.0, constant_softening=True, dt=1e-3, gamma=5.0 / 3.0,
+             vmax=1e16, mach_ceiling=1e5, dfloor=1e-10, pfloor=1e-12):
     prim = smooth_primitive(ni, nj, 4, extent) if smooth else random_primitive(seed, ni, nj, 4)
     cons = np.zeros_like(prim)
     cons[..., 0] = prim[..., 0]
@@ -107,8 +121,8 @@ def gam_case(seed=0, ni=32, nj=48, alpha=0.1, buffer_on=True, sink_model=2, a=0.
     return dict(
         shape=(ni, nj), extent=extent, prim=prim, cons=cons, gamma=gamma,
         buffer=(0.8, 0.05, m1[4] + m2[4], 1000.0, max(abs(extent[1]), abs(extent[3])), 0.5, int(buffer_on)),
-        m1=m1, m2=m2, alpha=alpha, a=a, dt=dt, vmax=1e16, cooling=cooling, mach_ceiling=1e5,
-        dfloor=1e-10, pfloor=1e-12, constant_softening=int(constant_softening),
+        m1=m1, m2=m2, alpha=alpha, a=a, dt=dt, vmax=vmax, cooling=cooling, mach_ceiling=mach_ceiling,
+        dfloor=dfloor, pfloor=pfloor, constant_softening=int(constant_softening),
     )
 
 
@@ -129,7 +143,38 @@ def gam_branch_matrix():
     combos.append(dict(ni=5, nj=3))
     combos.append(dict(ni=1, nj=1))
     combos.append(dict(ni=67, nj=131, smooth=True))
+    # limits engaged (cbdgam_2d.c:298-345): pressure floor, velocity ceiling, the full reset of zones whose
+    # density falls below the floor, and the Mach-ceiling floor of the cooling term (with and without cooling)
+    combos.append(dict(pfloor=0.7))
+    combos.append(dict(vmax=0.9, a=0.5))
+    combos.append(dict(dfloor=0.6))
+    combos.append(dict(dfloor=0.6, pfloor=0.7, vmax=0.9, a=0.5))
+    combos.append(dict(mach_ceiling=0.8))
+    combos.append(dict(mach_ceiling=0.8, cooling=1e-2, a=0.5, smooth=True))
+    combos.append(dict(mach_ceiling=0.8, cooling=1e-2, dfloor=0.6, pfloor=0.7, vmax=0.9, ni=67, nj=131))
     return combos
+
+
+def gam_limits_engaged(c, out):
+    """(zones reset by the density floor, zones on the pressure floor, zones with a velocity on the ceiling)."""
+    inner = out[NG:-NG, NG:-NG]
+    reset = (inner[..., 0] == c["dfloor"]) & (inner[..., 1] == 0.0) & (inner[..., 2] == 0.0) & (inner[..., 3] == c["pfloor"])
+    return (int(reset.sum()), int(((inner[..., 3] == c["pfloor"]) & ~reset).sum()),
+            int((np.abs(inner[..., 1:3]) == c["vmax"]).any(axis=-1).sum()))
+
+
+def component_relative_error(a, b, interior=True):
+    """
+    max over zones and fields of |a-b| / |b| where |b| is not negligible against the zone's largest field
+    (a component that is a rounding-level remainder of the zone's scale has no relative accuracy to speak of:
+    below 1e-6 of the zone's scale it is measured against that floor).
+    """
+    if interior:
+        a = a[NG:-NG, NG:-NG]
+        b = b[NG:-NG, NG:-NG]
+    scale = np.abs(b).max(axis=-1, keepdims=True)
+    den = np.maximum(np.abs(b), np.maximum(1e-6 * scale, 1e-300))
+    return float((np.abs(a - b) / den).max())
 
 
 def zone_relative_error(a, b, interior=True):

@@ -23,6 +23,42 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _run_ranks(target, args_of_rank, world=2, timeout=100):
+    """
+    Start `world` ranks, collect one queue item per rank, join.  Whatever happens (a hang, a failed rank, a
+    failed assertion) no child is left running: a rank that survives its test keeps the GPU and the gloo port
+    and would poison every later test on the box.
+    """
+    import queue as queue_module
+
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(*args_of_rank(r), queue)) for r in range(world)]
+    results = []
+    try:
+        for p in procs:
+            p.start()
+        for _ in range(world):  # drain before joining: a child blocks in exit until its queue item is read
+            try:
+                results.append(queue.get(timeout=timeout))
+            except queue_module.Empty:
+                break
+        for p in procs:
+            p.join(timeout=20)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert len(results) == world, f"{len(results)} of {world} ranks reported"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=5)
+    return results
+
+
 def _worker(rank, world, port, name, use_step, queue):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -54,9 +90,12 @@ def _worker(rank, world, port, name, use_step, queue):
                 dt = timestep(mesh, s, float(g["cfl"]))
                 s.advance(dt)
             worst = max(worst, abs(dt - dt_ref) / dt_ref)
-        final = s.solution
-        err = np.abs(final - g["final"]).max(axis=-1) / np.maximum(np.abs(g["final"]).max(axis=-1), 1e-300)
-        queue.put((rank, float(err.max()), worst))
+        final = s.solution  # collective; gathered on rank 0 only
+        if rank == 0:
+            err = np.abs(final - g["final"]).max(axis=-1) / np.maximum(np.abs(g["final"]).max(axis=-1), 1e-300)
+            queue.put((rank, float(err.max()), worst))
+        else:
+            queue.put((rank, 0.0 if final is None else float("inf"), worst))
     finally:
         dist.destroy_process_group()
 
@@ -65,18 +104,8 @@ def _worker(rank, world, port, name, use_step, queue):
 @pytest.mark.parametrize("name", ["iso_disk_128_p4", "gam_disk_64", "iso_disk_rk3_48"])
 def test_two_ranks_one_gpu(name, use_step):
     world = 2
-    ctx = mp.get_context("spawn")
-    queue = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, use_step, queue)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=100)
-    for p in procs:
-        assert p.exitcode == 0
-    for _ in range(world):
-        rank, err, dt_err = queue.get(timeout=5)
+    for rank, err, dt_err in _run_ranks(_worker, lambda r: (r, world, port, name, use_step), world):
         assert err <= 1e-12, (rank, err)
         assert dt_err <= 1e-13, (rank, dt_err)
 
@@ -100,7 +129,8 @@ def _dg_worker(rank, world, port, name, queue):
         for dt_ref in g["dt"]:
             dt = s.step(float(g["cfl"]))
             worst = max(worst, abs(dt - dt_ref) / dt_ref)
-        queue.put((rank, zone_error(s.solution, g["final"]), worst))
+        final = s.solution  # collective; gathered on rank 0 only
+        queue.put((rank, zone_error(final, g["final"]) if rank == 0 else (0.0 if final is None else float("inf")), worst))
     finally:
         dist.destroy_process_group()
 
@@ -110,17 +140,7 @@ def test_two_ranks_one_gpu_dg(name):
     """cbdisodg_2d: one-row halo slabs on the comm stream before the limiter and before the update,
     device-side dt behind the MAX all-reduce; against the reference's run."""
     world = 2
-    ctx = mp.get_context("spawn")
-    queue = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dg_worker, args=(r, world, port, name, queue)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=100)
-    for p in procs:
-        assert p.exitcode == 0
-    for _ in range(world):
-        rank, err, dt_err = queue.get(timeout=5)
+    for rank, err, dt_err in _run_ranks(_dg_worker, lambda r: (r, world, port, name), world):
         assert err <= 1e-12, (rank, err)
         assert dt_err <= 1e-13, (rank, dt_err)

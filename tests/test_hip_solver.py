@@ -16,8 +16,22 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 
+COMPONENT_TOL = 1e-9  # see tests/test_hip_kernels.py: each field against its own magnitude
+
+
 def zone_err(a, b):
     return float((np.abs(a - b).max(axis=-1) / np.maximum(np.abs(b).max(axis=-1), 1e-300)).max())
+
+
+def check(got, expect, tol=TOL):
+    """north_star's bar (1e-12 relative per zone) plus the per-component figure, printed with `pytest -s`."""
+    import cases
+
+    zerr = zone_err(got, expect)
+    cerr = cases.component_relative_error(got, expect, interior=False)
+    print(f"max relative error per zone {zerr:.2e}, per component {cerr:.2e}")
+    assert zerr <= tol, zerr
+    assert cerr <= COMPONENT_TOL, cerr
 
 
 def run_pair(setup_name, n, steps, model=None, options=None, num_patches=1, fused=True, cfl=None):
@@ -57,13 +71,13 @@ def run_pair(setup_name, n, steps, model=None, options=None, num_patches=1, fuse
 def test_iso_circumbinary_disk(fused, num_patches):
     got, expect = run_pair("circumbinary-disk", 128, 20, num_patches=num_patches, fused=fused)
     assert got.shape == (128, 128, 3)
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
 
 
 @pytest.mark.parametrize("rk_order", [1, 3])
 def test_iso_rk_orders(rk_order):
     got, expect = run_pair("circumbinary-disk", 96, 6, options=dict(rk_order=rk_order), num_patches=3)
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
 
 
 def test_iso_multi_patch_bitwise_equals_single_patch():
@@ -75,13 +89,13 @@ def test_iso_multi_patch_bitwise_equals_single_patch():
 
 def test_iso_cylindrical_explosion():
     got, expect = run_pair("cylindrical-explosion", 64, 20)
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
 
 
 def test_iso_eccentric_unequal_binary():
     got, expect = run_pair("circumbinary-disk", 96, 10, model=dict(eccentricity=0.3, mass_ratio=0.2, nu=0.0,
                                                                  sink_model="force_free"))
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -90,14 +104,14 @@ def test_gam_circumbinary_disk(fused, num_patches):
     got, expect = run_pair("circumbinary-disk", 96, 20, model=dict(eos="gamma-law"), num_patches=num_patches,
                            fused=fused)
     assert got.shape == (96, 96, 4)
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
 
 
 def test_gam_cooling_and_explosion():
     got, expect = run_pair("circumbinary-disk", 64, 10, model=dict(eos="gamma-law", cooling_coefficient=1e-2))
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
     got, expect = run_pair("cylindrical-explosion", 64, 20, model=dict(eos="gamma-law"))
-    assert zone_err(got, expect) <= TOL
+    check(got, expect)
 
 
 def test_restart_from_solution_is_bitwise():

@@ -27,6 +27,11 @@ def test_iso_advance_bitwise(kw):
     REF_ISO.call("cbdiso_2d_advance_rk", c["shape"], *cases.iso_advance_args(c, c["cons"], c["prim"], out_r))
     assert np.array_equal(out_o, out_r)
     assert np.all(out_o[:2] == -7.0) and np.all(out_o[:, :2] == -7.0)  # guards untouched
+    # the recovery's limits (cbdiso_2d.c:274-278) are really taken by the cases that ask for them
+    floored, capped = cases.iso_limits_engaged(c, out_r)
+    zones = c["shape"][0] * c["shape"][1]
+    assert floored >= zones // 50 if "dfloor" in kw else floored == 0, floored
+    assert capped >= zones // 50 if "vmax" in kw else capped == 0, capped
 
 
 @need_iso
@@ -54,6 +59,18 @@ def test_gam_advance_bitwise(kw):
     ORC.call("cbdgam_2d_advance_rk", c["shape"], *cases.gam_advance_args(c, c["cons"], c["prim"], out_o))
     REF_GAM.call("cbdgam_2d_advance_rk", c["shape"], *cases.gam_advance_args(c, c["cons"], c["prim"], out_r))
     assert np.array_equal(out_o, out_r, equal_nan=True)
+    # the limits of the recovery and of the cooling term (cbdgam_2d.c:314, 328-339) are really taken
+    reset, pfloored, capped = cases.gam_limits_engaged(c, out_r)
+    zones = c["shape"][0] * c["shape"][1]
+    assert reset >= zones // 50 if "dfloor" in kw else reset == 0, reset
+    assert pfloored >= zones // 50 if "pfloor" in kw else pfloored == 0, pfloored
+    assert capped >= zones // 50 if "vmax" in kw else capped == 0, capped
+    if "mach_ceiling" in kw:
+        free = cases.gam_case(seed=11, **dict(kw, mach_ceiling=1e5))
+        out_f = np.full_like(c["prim"], -7.0)
+        REF_GAM.call("cbdgam_2d_advance_rk", c["shape"], *cases.gam_advance_args(free, c["cons"], c["prim"], out_f))
+        raised = (out_r[2:-2, 2:-2, 3] > out_f[2:-2, 2:-2, 3]).sum()
+        assert raised > zones // 10, raised  # the Mach ceiling lifted the internal energy of these zones
 
 
 @need_gam

@@ -124,3 +124,35 @@ def test_hip_solver_restart_and_failure_report():
     c.patches[0].recompute_primitive()
     with pytest.raises(SolverError):
         c.check_failures()
+
+
+def _simulate_from_bad_state(**how):
+    from sailfish_amd.driver import simulate
+
+    setup = make_setup("envelope-shock", polar_extent=0.5)
+    mesh = setup.mesh(40)
+    kw = dict(setup=setup, mesh=mesh, num_patches=2, **how)
+    a = make_solver(setup.solver, setup.physics, {}, time=setup.start_time, **kw)
+    reports = list(simulate(a, mesh, fold=2, max_iterations=4))
+    assert len(reports) == 2  # a healthy run passes the per-fold check
+    bad = a.solution
+    bad[5, 3, 3] = -1.0  # negative energy: conserved_to_primitive cannot recover this zone
+    c = make_solver(setup.solver, setup.physics, {}, time=a.time, solution=bad, **kw)
+    return simulate(c, mesh, fold=2, max_iterations=4)
+
+
+def test_driver_surfaces_primitive_recovery_failures_cpu():
+    """The fold loop raises where the reference's kernel would have printed [FATAL] and exited."""
+    from oracle_backend import OracleBackend
+    from sailfish_amd.solvers.srhd_2d import SolverError
+
+    with pytest.raises(SolverError):
+        next(_simulate_from_bad_state(backend=OracleBackend(), distributed=False))
+
+
+@pytest.mark.gpu
+def test_driver_surfaces_primitive_recovery_failures_gpu():
+    from sailfish_amd.solvers.srhd_2d import SolverError
+
+    with pytest.raises(SolverError):
+        next(_simulate_from_bad_state(mode="hip"))
