@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 ADVANCE_TOL = 1e-12  # relative, per zone (BASELINE.json north_star)
 # Per component (each field against its own magnitude, cases.component_relative_error): one stage leaves a field
 # that is a near-cancelling sum of O(1) terms -- a velocity close to zero -- with an absolute error of a few
-# 1e-16 of the zone's scale, hence the looser bar; the per-zone figure above is north_star's.
+# 1e-16 of the zone's scale, hence the looser bar; the per-zone figure above is north_star's.  On these seeded
+# random states (no field anywhere near zero relative to its zone) 1e-9 is a real constraint.
 COMPONENT_TOL = 1e-9
 
 
