@@ -197,7 +197,14 @@ SFHIP_API int cbdiso_2d_wavespeed(
  * caller that sees a smaller value recomputes with *_max_wavespeed.  Pass 0 to
  * fold every zone.  dt_device, when not NULL, overrides `dt` with a timestep that
  * sfhip_timestep left in device memory, so the first stage of a step can be
- * launched before the host has read the wavespeed back. */
+ * launched before the host has read the wavespeed back.  amax_device, when not NULL
+ * (then dt_device must be NULL), goes one step further: the kernel forms the
+ * driver's `dt = dx / amax * cfl` (driver.py:509-510) itself from the reduced
+ * wavespeed in device memory -- dt_dx / *amax_device * dt_cfl, IEEE operations in
+ * that order, bit-identical to the host's -- so no separate timestep launch exists.
+ * zero_slot, when not NULL, is set to 0.0 by the launch: the slot the step's LAST
+ * stage will fold the next wavespeed into (want_wavespeed 1), which saves that
+ * stage's memset; it must not be the slot this launch itself folds into. */
 SFHIP_API int sfhip_cbdiso_2d_stage(
     int ni,
     int nj,
@@ -256,7 +263,11 @@ SFHIP_API int sfhip_cbdiso_2d_stage(
     double wmass2,
     double wsoftening_length2,
     double *wavespeed_max, // :: $.numel() >= 1
-    double *dt_device) // :: $.numel() >= 1
+    double *dt_device, // :: $.numel() >= 1
+    double *amax_device, // :: $.numel() >= 1
+    double dt_dx,
+    double dt_cfl,
+    double *zero_slot) // :: $.numel() >= 1
 ;
 
 /* Wavespeed kernel + max in one pass (no per-zone array): replaces the pair
@@ -440,7 +451,11 @@ SFHIP_API int sfhip_cbdgam_2d_stage(
     int want_wavespeed, // :: $ in [0, 1, 2]
     double wavespeed_floor, // :: $ >= 0.0
     double *wavespeed_max, // :: $.numel() >= 1
-    double *dt_device) // :: $.numel() >= 1
+    double *dt_device, // :: $.numel() >= 1
+    double *amax_device, // :: $.numel() >= 1
+    double dt_dx,
+    double dt_cfl,
+    double *zero_slot) // :: $.numel() >= 1
 ;
 
 SFHIP_API int sfhip_cbdgam_2d_max_wavespeed(
@@ -544,6 +559,50 @@ SFHIP_API int sfhip_reductions_workspace_len(
     int ni,
     int nj)
 ;
+
+/* ---------------------------------------------------------------- launch plans --
+ * No counterpart in the reference (its Patch marshals all 41/44 arguments per call,
+ * cbdiso_2d.py:198-238).  sfhip_cbd{iso,gam}_2d_stage take 60-odd scalars; through
+ * ctypes that costs the Python host ~20 us per launch, which bounds the step rate of
+ * small patches.  A plan stores what does not change between launches (mesh, physics
+ * constants, boundary clamps, stream) and sfhip_plan_stage passes only the arrays,
+ * the two masses, the RK parameter, dt, the row range and the wavespeed arguments;
+ * the launch is the same as the full entry point's (un_mode 2 whenever un_source is
+ * given).  Host-side arrays here are HOST pointers:
+ *   masses      18 doubles: x, y, vx, vy, mass, softening_length, sink_rate,
+ *               sink_radius, sink_model of mass 1, then of mass 2, at the stage time;
+ *   next_masses  8 doubles: x, y, mass, softening_length of the two masses at the time
+ *               the output state belongs to (cbdiso_2d with want_wavespeed; else NULL).
+ * A plan also owns 8 bytes of pinned host memory, a stream and two events for reading
+ * the reduced wavespeed back (sfhip_plan_fetch_begin / _wait) without torch's stream
+ * bookkeeping; these are created with the plan -- the per-step calls allocate nothing.
+ * create returns a plan id >= 0, or -1 (sfhip_last_error); the others 0 or an error.
+ * compute_stream / side_stream: hipStream_t the launches go to (on_side_stream 0 / 1).
+ */
+int sfhip_plan_create_cbdiso_2d(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double buffer_surface_density, double buffer_driving_rate, double buffer_outer_radius,
+    double buffer_onset_width, int buffer_is_enabled, double cs2, double mach_squared, int eos_type, double nu,
+    double velocity_ceiling, double density_floor, int clamp_ilo, int clamp_ihi, void *compute_stream);
+int sfhip_plan_create_cbdgam_2d(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr, double gamma_law_index,
+    double buffer_surface_density, double buffer_surface_pressure, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled, double alpha,
+    double velocity_ceiling, double cooling_coefficient, double mach_ceiling, double density_floor,
+    double pressure_floor, int constant_softening, int clamp_ilo, int clamp_ihi, void *compute_stream);
+int sfhip_plan_set_side_stream(int plan, void *side_stream);
+int sfhip_plan_destroy(int plan);
+int sfhip_plan_stage(int plan, const double *masses, const double *next_masses,
+                     double *un_source, double *primitive_rd, double *primitive_wr, double a, double dt,
+                     int i_begin, int i_end, int want_wavespeed, double wavespeed_floor, double *wavespeed_max,
+                     double *amax_device, double dt_dx, double dt_cfl, double *zero_slot, int on_side_stream,
+                     double host_seq);
+int sfhip_plan_fetch_begin(int plan, const double *device_scalar);
+int sfhip_plan_fetch_wait(int plan, double *host_value);
+/* host_seq != 0 (needs amax_device): as soon as the launch starts on the device one lane writes
+ * *amax_device and then host_seq to the plan's pinned memory, and sfhip_plan_host_wait(plan, host_seq, &v)
+ * returns that value: the host learns the reduced wavespeed without a copy or an event in the stream. */
+int sfhip_plan_host_wait(int plan, double host_seq, double *host_value);
 
 /* ---------------------------------------------------------------------------
  * srhd_2d -- 2-D special-relativistic hydrodynamics on a log-spherical, homologously

@@ -51,6 +51,35 @@ __device__ __forceinline__ double uniform_value(double x)
                             __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
+// dt = dx / amax * cfl in exactly the reference driver's operation order (driver.py:509-510), IEEE division,
+// nothing to contract; every lane computes the same value, which then lives in scalar registers.
+__device__ __forceinline__ double device_timestep(double dx, double amax, double cfl)
+{
+#pragma clang fp contract(off)
+    const double q = dx / amax;
+    return uniform_value(q * cfl);
+}
+
+// What one lane of a launch does besides the update when the step protocol asks for it (see IsoParams): zero
+// the slot the next wavespeed fold accumulates into, and hand the current reduced wavespeed to the host
+// through pinned memory: value first, then, after a system-scope fence, the sequence number the host waits for.
+__device__ __forceinline__ void step_bookkeeping(double *zero_ptr, double *host_out, double host_seq, const double *amax_ptr)
+{
+    if (zero_ptr) *zero_ptr = 0.0;
+    if (host_out) {
+        volatile double *out = host_out;
+        out[0] = *amax_ptr;
+        __threadfence_system();
+        out[1] = host_seq;
+    }
+}
+
+// the same as a launch of its own, for a stage launch that has no rows to update
+__global__ void step_bookkeeping_kernel(double *zero_ptr, double *host_out, double host_seq, const double *amax_ptr)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) step_bookkeeping(zero_ptr, host_out, host_seq, amax_ptr);
+}
+
 // C `?:` min/max of the reference (cbdiso_2d.c:16-17); NOT fmin/fmax.
 __device__ __forceinline__ double min2(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double max2(double a, double b) { return a > b ? a : b; }

@@ -36,6 +36,11 @@ struct GamParams {
     int rows_per_chunk, i_begin, i_end, want_wavespeed;
     double ws_floor; // zones slower than this are not folded in (see include/sfhip.h)
     const double *dt_ptr;       // when set, the timestep is read from device memory instead of `dt`
+    const double *amax_ptr;     // when set: dt = dt_dx / *amax_ptr * dt_cfl formed in the kernel (see IsoParams)
+    double dt_dx, dt_cfl;
+    double *zero_ptr;           // when set, one lane stores 0.0 there
+    double *host_out;           // when set (with amax_ptr): *amax_ptr, then host_seq, to pinned host memory (see IsoParams)
+    double host_seq;
     // uniform values evaluated on the host so that they arrive in SGPRs (no scalar fp64 unit: formed
     // in the kernel they would sit in vector registers for the whole march)
     double half_inv_dx, half_inv_dy, one_minus_a, inv_buf_sd, sink_near2[2]; // sink_near2 = (4 r_sink)^2
@@ -336,6 +341,8 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return;
     if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
+    if (P.amax_ptr) P.dt = device_timestep(P.dt_dx, *P.amax_ptr, P.dt_cfl);
+    if (gw == 0 && lane == 0) step_bookkeeping(P.zero_ptr, P.host_out, P.host_seq, P.amax_ptr);
     // the parameter block again, through a pointer of hidden origin: loads through it stay inside the
     // rarely taken branches that need them (see sf_iso.hpp)
     const GamParams *Pk = (const GamParams *)__builtin_amdgcn_kernarg_segment_ptr();

@@ -47,6 +47,15 @@ struct IsoParams {
     int want_wavespeed;         // fold max wavespeed of the OUTPUT state into *wmax
     double ws_floor;            // zones slower than this are not folded in (see include/sfhip.h)
     const double *dt_ptr;       // when set, the timestep is read from device memory instead of `dt`
+    // when amax_ptr is set, the timestep is FORMED here from the reduced wavespeed in device memory:
+    // dt = dt_dx / *amax_ptr * dt_cfl, the driver's expression (driver.py:509-510) in IEEE operations
+    const double *amax_ptr;
+    double dt_dx, dt_cfl;
+    double *zero_ptr;           // when set, one lane stores 0.0 there (the slot the NEXT fold accumulates into)
+    // when set (with amax_ptr): one lane writes *amax_ptr to host_out[0] and then host_seq to host_out[1] --
+    // pinned host memory the host polls, so it learns the reduced wavespeed without a copy or an event
+    double *host_out;
+    double host_seq;
     Mass mw[2];                 // masses at the time the output state belongs to (for want_wavespeed)
 };
 
@@ -238,6 +247,8 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     const int chunk = gw / nstrips;
     if (chunk >= nchunks) return; // whole wave leaves together
     if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
+    if (P.amax_ptr) P.dt = device_timestep(P.dt_dx, *P.amax_ptr, P.dt_cfl);
+    if (gw == 0 && lane == 0) step_bookkeeping(P.zero_ptr, P.host_out, P.host_seq, P.amax_ptr);
     // The same parameter block, addressed through a pointer whose origin the optimiser cannot see:
     // loads through it stay inside the rarely taken branches that need them (sink interior, exact
     // wavespeed) instead of being hoisted into SGPRs that the whole march would then have to spill.

@@ -11,6 +11,7 @@
 //   * entry points return 0 on success, a hipError_t value (or -1 for argument
 //     errors) otherwise; sfhip_last_error() describes the last failure.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -102,7 +103,15 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
     const int nrows = P.i_end - P.i_begin;
-    if (nrows == 0) return 0;
+    if (P.host_out && !P.amax_ptr) return fail(-1, "stage: the host hand-over needs amax_device");
+    if (nrows == 0) {
+        if (P.zero_ptr || P.host_out) { // the step protocol's bookkeeping must happen even when no row is updated
+            hipLaunchKernelGGL(sf::step_bookkeeping_kernel, dim3(1), dim3(64), 0, t_stream, P.zero_ptr, P.host_out,
+                               P.host_seq, P.amax_ptr);
+            return check_launch("step_bookkeeping_kernel");
+        }
+        return 0;
+    }
     const int nstrips = (P.nj + sf::STRIP - 1) / sf::STRIP;
     int nchunks;
     plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
@@ -146,7 +155,15 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
     const int nrows = P.i_end - P.i_begin;
-    if (nrows == 0) return 0;
+    if (P.host_out && !P.amax_ptr) return fail(-1, "stage: the host hand-over needs amax_device");
+    if (nrows == 0) {
+        if (P.zero_ptr || P.host_out) { // the step protocol's bookkeeping must happen even when no row is updated
+            hipLaunchKernelGGL(sf::step_bookkeeping_kernel, dim3(1), dim3(64), 0, t_stream, P.zero_ptr, P.host_out,
+                               P.host_seq, P.amax_ptr);
+            return check_launch("step_bookkeeping_kernel");
+        }
+        return 0;
+    }
     const int nstrips = (P.nj + sf::STRIP - 1) / sf::STRIP;
     int nchunks;
     plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
@@ -403,8 +420,12 @@ int sfhip_cbdiso_2d_stage(
     double wavespeed_floor,
     double wx1, double wy1, double wmass1, double wsoftening_length1,
     double wx2, double wy2, double wmass2, double wsoftening_length2,
-    double *wavespeed_max, double *dt_device)
+    double *wavespeed_max, double *dt_device,
+    double *amax_device, double dt_dx, double dt_cfl, double *zero_slot)
 {
+    if (zero_slot && want_wavespeed && zero_slot == wavespeed_max)
+        return fail(-1, "sfhip_cbdiso_2d_stage: zero_slot must not be the slot this launch folds into");
+    if (amax_device && dt_device) return fail(-1, "sfhip_cbdiso_2d_stage: give dt_device or amax_device, not both");
     sf::IsoParams P;
     fill_iso(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr,
              buffer_surface_density, buffer_central_mass, buffer_driving_rate, buffer_outer_radius,
@@ -420,6 +441,7 @@ int sfhip_cbdiso_2d_stage(
     P.mw[0] = make_mass(wx1, wy1, 0, 0, wmass1, wsoftening_length1, 0, 0, 0);
     P.mw[1] = make_mass(wx2, wy2, 0, 0, wmass2, wsoftening_length2, 0, 0, 0);
     P.dt_ptr = dt_device;
+    P.amax_ptr = amax_device; P.dt_dx = dt_dx; P.dt_cfl = dt_cfl; P.zero_ptr = zero_slot;
     return launch_iso_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
 }
 
@@ -536,8 +558,12 @@ int sfhip_cbdgam_2d_stage(
     double alpha, double a, double dt, double velocity_ceiling, double cooling_coefficient,
     double mach_ceiling, double density_floor, double pressure_floor, int constant_softening,
     int un_mode, int clamp_ilo, int clamp_ihi, int i_begin, int i_end, int want_wavespeed,
-    double wavespeed_floor, double *wavespeed_max, double *dt_device)
+    double wavespeed_floor, double *wavespeed_max, double *dt_device,
+    double *amax_device, double dt_dx, double dt_cfl, double *zero_slot)
 {
+    if (zero_slot && want_wavespeed && zero_slot == wavespeed_max)
+        return fail(-1, "sfhip_cbdgam_2d_stage: zero_slot must not be the slot this launch folds into");
+    if (amax_device && dt_device) return fail(-1, "sfhip_cbdgam_2d_stage: give dt_device or amax_device, not both");
     sf::GamParams P;
     fill_gam(P, ni, nj, patch_xl, patch_xr, patch_yl, patch_yr, gamma_law_index,
              buffer_surface_density, buffer_surface_pressure, buffer_central_mass, buffer_driving_rate,
@@ -552,6 +578,7 @@ int sfhip_cbdgam_2d_stage(
     P.want_wavespeed = want_wavespeed;
     P.ws_floor = wavespeed_floor;
     P.dt_ptr = dt_device;
+    P.amax_ptr = amax_device; P.dt_dx = dt_dx; P.dt_cfl = dt_cfl; P.zero_ptr = zero_slot;
     return launch_gam_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
 }
 
@@ -603,6 +630,264 @@ int cbdgam_2d_point_mass_source_term(
     return check_launch("cbdgam_2d_point_mass_source_term");
 }
 
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// Launch plans: the fused stage with its constant arguments stored once.
+//
+// sfhip_cbd{iso,gam}_2d_stage take 60-odd scalars per call; marshalling them through ctypes costs the Python
+// host ~20 us per launch, which is what bounds the step rate of small patches (512^2 on one GPU; the slabs of a
+// strong-scaling run).  A plan keeps what does not change between launches -- mesh, physics constants, boundary
+// flags, streams -- and a launch passes only the arrays, the two masses, the RK parameter, dt, the row range and
+// the wavespeed arguments.  The launch itself is the very same launch_{iso,gam}_stage as the full entry point's.
+// A plan also owns what the host needs to read the reduced wavespeed back without torch's stream/event
+// bookkeeping: 8 bytes of pinned host memory, a stream and two events, created with the plan (the only
+// allocations; the per-step calls allocate nothing).
+// ---------------------------------------------------------------------------
+namespace {
+
+struct StagePlan {
+    int kind = 0; // 0 free, 1 cbdiso_2d, 2 cbdgam_2d
+    int device = 0;
+    int ni = 0, nj = 0;
+    double xl = 0, xr = 0, yl = 0, yr = 0;
+    double bsd = 0, bsp = 0, brate = 0, brout = 0, bw = 0;
+    int bon = 0;
+    double cs2 = 0, mach2 = 0;
+    int eos = 0;
+    double nu = 0, vmax = 0, dfloor = 0;
+    double gamma = 0, alpha = 0, cooling = 0, mach_ceiling = 0, pfloor = 0;
+    int constant_softening = 0;
+    int clamp_ilo = 0, clamp_ihi = 0;
+    hipStream_t compute = nullptr, side = nullptr, fetch = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    double *pinned = nullptr;     // host view: [0] fetched value; [2] value and [3] sequence number written by a stage
+    double *pinned_dev = nullptr; // device view of the same memory
+};
+
+constexpr int MAX_PLANS = 1024;
+StagePlan g_plans[MAX_PLANS];
+std::mutex g_plan_mutex;
+
+StagePlan *plan_of(int id)
+{
+    if (id < 0 || id >= MAX_PLANS || g_plans[id].kind == 0) {
+        fail(-1, "sfhip_plan: no such plan");
+        return nullptr;
+    }
+    return &g_plans[id];
+}
+
+int plan_alloc(StagePlan **out)
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    for (int id = 0; id < MAX_PLANS; ++id) {
+        if (g_plans[id].kind == 0) {
+            StagePlan &pl = g_plans[id];
+            pl = StagePlan();
+            hipError_t e = hipGetDevice(&pl.device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl.fetch, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&pl.ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&pl.done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&pl.pinned, 8 * sizeof(double), hipHostMallocDefault);
+            if (e == hipSuccess) {
+                memset(pl.pinned, 0, 8 * sizeof(double));
+                e = hipHostGetDevicePointer((void **)&pl.pinned_dev, pl.pinned, 0);
+            }
+            if (e != hipSuccess) {
+                if (pl.pinned) (void)hipHostFree(pl.pinned);
+                if (pl.done) (void)hipEventDestroy(pl.done);
+                if (pl.ready) (void)hipEventDestroy(pl.ready);
+                if (pl.fetch) (void)hipStreamDestroy(pl.fetch);
+                pl = StagePlan();
+                fail((int)e, hipGetErrorString(e));
+                return -1;
+            }
+            pl.kind = -1; // taken; the caller sets the real kind
+            *out = &pl;
+            return id;
+        }
+    }
+    fail(-1, "sfhip_plan: too many plans");
+    return -1;
+}
+
+sf::Mass mass_from(const double *m)
+{
+    return make_mass(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], (int)m[8]);
+}
+
+} // namespace
+
+extern "C" {
+
+int sfhip_plan_create_cbdiso_2d(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double buffer_surface_density, double buffer_driving_rate, double buffer_outer_radius,
+    double buffer_onset_width, int buffer_is_enabled, double cs2, double mach_squared, int eos_type, double nu,
+    double velocity_ceiling, double density_floor, int clamp_ilo, int clamp_ihi, void *compute_stream)
+{
+    if (ni < 1 || nj < 1) return fail(-1, "sfhip_plan_create_cbdiso_2d: ni, nj must be >= 1");
+    StagePlan *pl = nullptr;
+    const int id = plan_alloc(&pl);
+    if (id < 0) return id;
+    pl->ni = ni; pl->nj = nj; pl->xl = patch_xl; pl->xr = patch_xr; pl->yl = patch_yl; pl->yr = patch_yr;
+    pl->bsd = buffer_surface_density; pl->brate = buffer_driving_rate; pl->brout = buffer_outer_radius;
+    pl->bw = buffer_onset_width; pl->bon = buffer_is_enabled;
+    pl->cs2 = cs2; pl->mach2 = mach_squared; pl->eos = eos_type; pl->nu = nu;
+    pl->vmax = velocity_ceiling; pl->dfloor = density_floor;
+    pl->clamp_ilo = clamp_ilo; pl->clamp_ihi = clamp_ihi;
+    pl->compute = (hipStream_t)compute_stream;
+    pl->side = (hipStream_t)compute_stream;
+    pl->kind = 1;
+    return id;
+}
+
+int sfhip_plan_create_cbdgam_2d(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr, double gamma_law_index,
+    double buffer_surface_density, double buffer_surface_pressure, double buffer_driving_rate,
+    double buffer_outer_radius, double buffer_onset_width, int buffer_is_enabled, double alpha,
+    double velocity_ceiling, double cooling_coefficient, double mach_ceiling, double density_floor,
+    double pressure_floor, int constant_softening, int clamp_ilo, int clamp_ihi, void *compute_stream)
+{
+    if (ni < 1 || nj < 1) return fail(-1, "sfhip_plan_create_cbdgam_2d: ni, nj must be >= 1");
+    StagePlan *pl = nullptr;
+    const int id = plan_alloc(&pl);
+    if (id < 0) return id;
+    pl->ni = ni; pl->nj = nj; pl->xl = patch_xl; pl->xr = patch_xr; pl->yl = patch_yl; pl->yr = patch_yr;
+    pl->gamma = gamma_law_index;
+    pl->bsd = buffer_surface_density; pl->bsp = buffer_surface_pressure; pl->brate = buffer_driving_rate;
+    pl->brout = buffer_outer_radius; pl->bw = buffer_onset_width; pl->bon = buffer_is_enabled;
+    pl->alpha = alpha; pl->vmax = velocity_ceiling; pl->cooling = cooling_coefficient;
+    pl->mach_ceiling = mach_ceiling; pl->dfloor = density_floor; pl->pfloor = pressure_floor;
+    pl->constant_softening = constant_softening;
+    pl->clamp_ilo = clamp_ilo; pl->clamp_ihi = clamp_ihi;
+    pl->compute = (hipStream_t)compute_stream;
+    pl->side = (hipStream_t)compute_stream;
+    pl->kind = 2;
+    return id;
+}
+
+int sfhip_plan_set_side_stream(int plan, void *side_stream)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl) return -1;
+    pl->side = (hipStream_t)side_stream;
+    return 0;
+}
+
+int sfhip_plan_destroy(int plan)
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    StagePlan *pl = plan_of(plan);
+    if (!pl) return -1;
+    (void)hipEventSynchronize(pl->done);
+    (void)hipHostFree(pl->pinned);
+    (void)hipEventDestroy(pl->done);
+    (void)hipEventDestroy(pl->ready);
+    (void)hipStreamDestroy(pl->fetch);
+    *pl = StagePlan();
+    return 0;
+}
+
+// masses: 18 host doubles, (x, y, vx, vy, mass, softening_length, sink_rate, sink_radius, sink_model) of mass 1,
+// then of mass 2, at the stage time; next_masses: 8 host doubles, (x, y, mass, softening_length) of the two masses
+// at the time the output state belongs to (cbdiso_2d with want_wavespeed only; may be NULL otherwise).
+// Everything else as in sfhip_cbd{iso,gam}_2d_stage; un_mode is 2 when un_source is given.
+int sfhip_plan_stage(int plan, const double *masses, const double *next_masses,
+                     double *un_source, double *primitive_rd, double *primitive_wr, double a, double dt,
+                     int i_begin, int i_end, int want_wavespeed, double wavespeed_floor, double *wavespeed_max,
+                     double *amax_device, double dt_dx, double dt_cfl, double *zero_slot, int on_side_stream,
+                     double host_seq)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl) return -1;
+    if (!masses) return fail(-1, "sfhip_plan_stage: null masses");
+    if (host_seq != 0.0 && !amax_device) return fail(-1, "sfhip_plan_stage: host_seq needs amax_device");
+    if (zero_slot && want_wavespeed && zero_slot == wavespeed_max)
+        return fail(-1, "sfhip_plan_stage: zero_slot must not be the slot this launch folds into");
+    const sf::Mass m1 = mass_from(masses), m2 = mass_from(masses + 9);
+    const hipStream_t saved = t_stream;
+    t_stream = on_side_stream ? pl->side : pl->compute;
+    int rc;
+    if (pl->kind == 1) {
+        sf::IsoParams P;
+        fill_iso(P, pl->ni, pl->nj, pl->xl, pl->xr, pl->yl, pl->yr, pl->bsd, m1.mass + m2.mass /* cbdiso_2d.py:194 */,
+                 pl->brate, pl->brout, pl->bw, pl->bon, m1, m2, pl->cs2, pl->mach2, pl->eos, pl->nu, a, dt, pl->vmax,
+                 pl->dfloor);
+        P.un_mode = a != 0.0 && un_source ? 2 : 0;
+        P.clamp_ilo = pl->clamp_ilo; P.clamp_ihi = pl->clamp_ihi; P.clamp_j = 1;
+        P.i_begin = i_begin; P.i_end = i_end;
+        P.want_wavespeed = want_wavespeed;
+        P.ws_floor = wavespeed_floor;
+        if (want_wavespeed) {
+            if (!next_masses) { t_stream = saved; return fail(-1, "sfhip_plan_stage: want_wavespeed needs next_masses"); }
+            P.mw[0] = make_mass(next_masses[0], next_masses[1], 0, 0, next_masses[2], next_masses[3], 0, 0, 0);
+            P.mw[1] = make_mass(next_masses[4], next_masses[5], 0, 0, next_masses[6], next_masses[7], 0, 0, 0);
+        }
+        P.amax_ptr = amax_device; P.dt_dx = dt_dx; P.dt_cfl = dt_cfl; P.zero_ptr = zero_slot;
+        if (host_seq != 0.0) { P.host_out = pl->pinned_dev + 2; P.host_seq = host_seq; }
+        rc = launch_iso_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
+    } else {
+        sf::GamParams P;
+        fill_gam(P, pl->ni, pl->nj, pl->xl, pl->xr, pl->yl, pl->yr, pl->gamma, pl->bsd, pl->bsp,
+                 m1.mass + m2.mass /* cbdgam_2d.py:164 */, pl->brate, pl->brout, pl->bw, pl->bon, m1, m2, pl->alpha, a,
+                 dt, pl->vmax, pl->cooling, pl->mach_ceiling, pl->dfloor, pl->pfloor, pl->constant_softening);
+        P.un_mode = a != 0.0 && un_source ? 2 : 0;
+        P.clamp_ilo = pl->clamp_ilo; P.clamp_ihi = pl->clamp_ihi; P.clamp_j = 1;
+        P.i_begin = i_begin; P.i_end = i_end;
+        P.want_wavespeed = want_wavespeed;
+        P.ws_floor = wavespeed_floor;
+        P.amax_ptr = amax_device; P.dt_dx = dt_dx; P.dt_cfl = dt_cfl; P.zero_ptr = zero_slot;
+        if (host_seq != 0.0) { P.host_out = pl->pinned_dev + 2; P.host_seq = host_seq; }
+        rc = launch_gam_stage(P, primitive_rd, un_source, primitive_wr, wavespeed_max);
+    }
+    t_stream = saved;
+    return rc;
+}
+
+// Start copying one device double to the plan's pinned host word on the plan's own stream, ordered behind
+// everything queued on the compute stream so far and nothing queued later.
+int sfhip_plan_fetch_begin(int plan, const double *device_scalar)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl || !device_scalar) return pl ? fail(-1, "sfhip_plan_fetch_begin: null pointer") : -1;
+    hipError_t e = hipEventRecord(pl->ready, pl->compute);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pl->fetch, pl->ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(pl->pinned, device_scalar, sizeof(double), hipMemcpyDeviceToHost, pl->fetch);
+    if (e == hipSuccess) e = hipEventRecord(pl->done, pl->fetch);
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+// Block until the copy started by sfhip_plan_fetch_begin has arrived; the value goes to *host_value.
+int sfhip_plan_fetch_wait(int plan, double *host_value)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl || !host_value) return pl ? fail(-1, "sfhip_plan_fetch_wait: null pointer") : -1;
+    hipError_t e = hipEventSynchronize(pl->done);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    *host_value = *pl->pinned;
+    return 0;
+}
+
+// Block until a stage launched with this `host_seq` has started on the device and handed the reduced wavespeed
+// over through the plan's pinned memory (no copy, no event: the host polls two words).  Gives up after 30 s.
+int sfhip_plan_host_wait(int plan, double host_seq, double *host_value)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl || !host_value) return pl ? fail(-1, "sfhip_plan_host_wait: null pointer") : -1;
+    volatile double *word = pl->pinned + 2;
+    const auto start = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0; word[1] != host_seq; ++spins) {
+        if ((spins & 0xfffff) == 0xfffff &&
+            std::chrono::steady_clock::now() - start > std::chrono::seconds(30))
+            return fail(-1, "sfhip_plan_host_wait: no stage reported within 30 s (was one launched with this host_seq?)");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *host_value = word[0];
+    return 0;
+}
 
 } // extern "C"
 

@@ -1,0 +1,116 @@
+"""
+Launch plans: the fused stage entry points with their constant arguments marshalled once.
+
+``Library``'s ``kernel[shape](*args)`` converts every one of the 60-odd arguments of
+``sfhip_cbd{iso,gam}_2d_stage`` on every call and looks torch's current stream up (about 20 us of
+Python per launch).  That is the reference's calling convention and stays the drop-in path; the
+device-resident solvers launch through a ``StagePlan`` instead (include/sfhip.h, "launch plans"):
+constants go to the C side when the patch is created, a launch passes the arrays, the two masses
+and a dozen scalars.  The same C function performs the launch either way.
+"""
+import ctypes
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+def _bind(module):
+    """ctypes signatures of the plan entry points (declared as plain C in include/sfhip.h)."""
+    if getattr(module, "_sfhip_plan_bound", False):
+        return
+    i, d, p = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+    module.sfhip_plan_create_cbdiso_2d.argtypes = [i, i, d, d, d, d, d, d, d, d, i, d, d, i, d, d, d, i, i, p]
+    module.sfhip_plan_create_cbdgam_2d.argtypes = [i, i, d, d, d, d, d, d, d, d, d, d, i, d, d, d, d, d, d, i, i, i, p]
+    module.sfhip_plan_set_side_stream.argtypes = [i, p]
+    module.sfhip_plan_destroy.argtypes = [i]
+    module.sfhip_plan_stage.argtypes = [i, _c_double_p, _c_double_p, p, p, p, d, d, i, i, i, d, p, p, d, d, p, i, d]
+    module.sfhip_plan_host_wait.argtypes = [i, d, _c_double_p]
+    module.sfhip_plan_fetch_begin.argtypes = [i, p]
+    module.sfhip_plan_fetch_wait.argtypes = [i, _c_double_p]
+    for name in ("create_cbdiso_2d", "create_cbdgam_2d", "set_side_stream", "destroy", "stage", "fetch_begin",
+                 "fetch_wait", "host_wait"):
+        getattr(module, "sfhip_plan_" + name).restype = i
+    module._sfhip_plan_bound = True
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class StagePlan:
+    """One patch's plan.  Created with the patch's device current; launches go to the stream that was
+    torch's current stream at that moment (``on_side_stream``: to the stream given to ``set_side_stream``)."""
+
+    def __init__(self, lib, patch, kind):
+        import torch
+
+        from .library import KernelError
+
+        self._error = KernelError
+        self.lib = lib
+        self.module = module = lib.module
+        _bind(module)
+        stream = torch.cuda.current_stream().cuda_stream
+        create = module.sfhip_plan_create_cbdiso_2d if kind == "cbdiso_2d" else module.sfhip_plan_create_cbdgam_2d
+        self.id = create(*patch.plan_constants(), ctypes.c_void_p(stream))
+        if self.id < 0:
+            raise KernelError(f"sfhip_plan_create_{kind} failed: {lib.last_error()}")
+        self._stage = module.sfhip_plan_stage
+        self._masses = (ctypes.c_double * 18)()
+        self._next = (ctypes.c_double * 8)()
+        self._packed = (None, None)
+        self._packed_next = (None, None)
+        self._host_value = ctypes.c_double(0.0)
+        self._host_ref = ctypes.byref(self._host_value)
+
+    def close(self):
+        if self.id >= 0:
+            self.module.sfhip_plan_destroy(self.id)
+            self.id = -1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_side_stream(self, stream):
+        self.module.sfhip_plan_set_side_stream(self.id, ctypes.c_void_p(stream.cuda_stream))
+
+    def stage(self, patch, m1, m2, w1, w2, un, rd, wr, rk_param, dt, i_begin, i_end, want_wavespeed, floor, wmax,
+              amax_device, dt_dx, dt_cfl, zero_slot, on_side_stream, host_seq=0.0):
+        """Marshal now, launch later: returns the zero-argument callable that performs the C call."""
+        if self._packed[0] is not m1 or self._packed[1] is not m2:  # same tuple objects for a given time
+            self._masses[:] = [float(v) for v in (*m1.kernel_args(), *m2.kernel_args())]
+            self._packed = (m1, m2)
+        nxt = None
+        if want_wavespeed and w1 is not None:
+            if self._packed_next[0] is not w1 or self._packed_next[1] is not w2:
+                self._next[:] = [w1.position_x, w1.position_y, w1.mass, w1.softening_length,
+                                 w2.position_x, w2.position_y, w2.mass, w2.softening_length]
+                self._packed_next = (w1, w2)
+            nxt = self._next
+        args = (self.id, self._masses, nxt, _ptr(un), rd.data_ptr(), wr.data_ptr(), rk_param, dt, i_begin, i_end,
+                want_wavespeed, floor, _ptr(wmax), _ptr(amax_device), dt_dx, dt_cfl, _ptr(zero_slot),
+                1 if on_side_stream else 0, host_seq)
+
+        def fire():
+            status = self._stage(*args)
+            if status != 0:
+                raise self._error(f"sfhip_plan_stage failed ({status}): {self.lib.last_error()}")
+
+        return fire
+
+    def host_wait(self, host_seq):
+        """The reduced wavespeed handed over by the stage that was launched with this `host_seq`."""
+        if self.module.sfhip_plan_host_wait(self.id, host_seq, self._host_ref) != 0:
+            raise self._error(f"sfhip_plan_host_wait failed: {self.lib.last_error()}")
+        return self._host_value.value
+
+    def fetch_begin(self, scalar):
+        if self.module.sfhip_plan_fetch_begin(self.id, scalar.data_ptr()) != 0:
+            raise self._error(f"sfhip_plan_fetch_begin failed: {self.lib.last_error()}")
+
+    def fetch_wait(self):
+        if self.module.sfhip_plan_fetch_wait(self.id, self._host_ref) != 0:
+            raise self._error(f"sfhip_plan_fetch_wait failed: {self.lib.last_error()}")
+        return self._host_value.value

@@ -94,13 +94,17 @@ class _HipDevice:
     def __enter__(self):
         import torch
 
+        if torch.cuda.current_device() == self.device_id:  # the usual case (one process per GPU): nothing to switch
+            self._stack.append(None)
+            return self
         guard = torch.cuda.device(self.device_id)
         guard.__enter__()
         self._stack.append(guard)
         return self
 
     def __exit__(self, *exc):
-        return self._stack.pop().__exit__(*exc)
+        guard = self._stack.pop()
+        return None if guard is None else guard.__exit__(*exc)
 
 
 def execution_context(mode, device_id=None):

@@ -30,6 +30,7 @@ on rank ``k * world // num_patches``; halo slabs between ranks travel as
 them are updated, and dt is a MAX all-reduce of one double.
 """
 import contextlib
+import os
 from logging import getLogger
 
 import numpy as np
@@ -202,6 +203,7 @@ class PatchBase:
                 self.wavespeeds = xp.zeros(primitive.shape[:2])
         self._coords = None
         self._reduce_workspace = None
+        self.plan = None  # launch plan of the fused stage (device runs; see kernel/plan.py)
 
     @property
     def primitive(self):
@@ -320,8 +322,6 @@ class SolverBase:
 
         ndev = backend.num_devices()
         if self.comm.enabled and backend.mode == "hip":
-            import os
-
             base_device = int(os.environ.get("LOCAL_RANK", self.comm.rank % max(ndev, 1)))
         else:
             base_device = None
@@ -343,9 +343,21 @@ class SolverBase:
             )
             self.patches.append(patch)
         self._comm_stream = None
+        if backend.mode == "hip" and fused and not os.environ.get("SFHIP_NO_PLANS"):
+            from ..kernel.plan import StagePlan
+
+            for p in self.patches:
+                with p.execution_context:
+                    p.plan = StagePlan(p.lib, p, type(self).__module__.rsplit(".", 1)[-1])
         self._mass_cache = (None, None)
         self._wavespeed_floor = 0.0
         self._dt_dev = None
+        self._slots = None        # two device doubles: the reduced wavespeed of the current / next state (step())
+        self._slot_views = None
+        self._slot_cur = 0
+        self._slot_valid = False  # slot[_slot_cur] holds the global maximum wavespeed of the current state
+        self._dt_dx = self._dt_cfl = 0.0
+        self._host_seq = 0.0
         self._fetch_stream = None
         self._remote_neighbors = None
         self.event_log = None  # bench.py sets this to a list to time every stage launch with HIP events
@@ -473,6 +485,11 @@ class SolverBase:
         is not below that floor, which is checked here on the global value.
         """
         floor = self._wavespeed_floor
+        if self._slot_valid:  # left by step(): already reduced over patches and ranks
+            value = float(self._slot_views[self._slot_cur].item())
+            if not value < floor:
+                self._wavespeed_floor = 0.5 * value
+                return value
         have_fused = self.fused and all(p.wavespeed_valid for p in self.patches)
         value = self._reduce_wavespeed(recompute=not have_fused)
         if have_fused and value < floor:
@@ -518,7 +535,13 @@ class SolverBase:
             with p.execution_context:
                 p.new_iteration()
 
-    def advance_rk(self, rk_param, dt, stage=0, nstages=1, dt_device=None):
+    def advance_rk(self, rk_param, dt, stage=0, nstages=1, slots=None, host_seq=0.0):
+        """
+        One RK stage on every local patch.  `slots` (Solver.step only) = (current, next) one-element views
+        of the device-side wavespeed slots: stage 0 then forms dt in the kernel from `current` and zeroes
+        `next`, and the last stage folds the new maximum into `next` (see step()).
+        """
+        self._slot_valid = False
         if not self.fused:
             self.set_bc("primitive1")
             for p in self.patches:
@@ -531,12 +554,20 @@ class SolverBase:
         # stream, right behind the receives, concurrently with the interior launch on the compute
         # stream -- neither the halo latency nor the thin boundary launches sit on the critical path.
         side = self.backend.mode == "hip" and self._has_remote_neighbors()
-        if side and last_stage:
+        if side and last_stage and slots is None:
             # the wavespeed fold is then shared by launches on two streams: reset it before either starts
             for p in self.patches:
                 with p.execution_context:
                     p.wavespeed_max.zero_()
         plans = []
+        # what the launches of this stage get beyond the state: where dt comes from, what to zero, where to fold
+        extra = {}
+        if slots is not None:
+            if stage == 0:
+                extra = dict(amax_device=slots[0], dt_dx=self._dt_dx, dt_cfl=self._dt_cfl, zero_slot=slots[1])
+            if last_stage:
+                extra["fold_into"] = slots[1]
+        accumulate = side or slots is not None  # the fold target has been zeroed already: never memset it
 
         def launch_interiors():
             for p in self.patches:
@@ -547,9 +578,12 @@ class SolverBase:
                 masses = self.point_masses(p.time)
                 next_masses = self.point_masses(p.stage_time(rk_param, dt)) if last_stage else masses
                 plans.append((p, lo, hi, rd, un, wr, masses, next_masses))
+                ex = extra
+                if host_seq and p is self.patches[0]:
+                    ex = dict(extra, host_seq=host_seq)  # this launch hands the reduced wavespeed to the host
                 with p.execution_context:
                     self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, lo, hi,
-                                 (1 if side else 2) if last_stage else 0, dt_device)
+                                 (1 if accumulate else 2) if last_stage else 0, ex)
 
         if side:
             # The transport calls cost the host ~0.15 ms per exchange on RCCL (tools/p2p_cost.py), half a stage
@@ -568,15 +602,15 @@ class SolverBase:
                 with stream:
                     if lo > 0:
                         self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, 0, lo,
-                                     1 if last_stage else 0, dt_device)
+                                     1 if last_stage else 0, extra, side)
                     if hi < ni:
                         self._launch(p, rk_param, dt, rd, un, wr, masses, next_masses, hi, ni,
-                                     1 if last_stage else 0, dt_device)
+                                     1 if last_stage else 0, extra, side)
                 if side:
                     torch.cuda.current_stream().wait_stream(self._comm_stream)  # the stage is complete on both
-            if dt_device is None:
+            if "amax_device" not in extra:
                 p.finish_stage(rk_param, dt, wr)
-            p.wavespeed_valid = last_stage
+            p.wavespeed_valid = last_stage and slots is None
         return [plan[5] for plan in plans]
 
     def _has_remote_neighbors(self):
@@ -589,10 +623,15 @@ class SolverBase:
     def step(self, cfl_number, dx=None):
         """
         One driver iteration -- ``dt = dx / maximum_wavespeed() * cfl; advance(dt)`` (driver.py:508-511)
-        -- with the wavespeed read-back taken off the critical path: dt is also evaluated on the device
-        (same IEEE operations, sfhip_timestep), the first RK stage is launched against that device value,
-        and only then does the host read the wavespeed back to form the identical dt for its own
-        bookkeeping (time, point-mass positions of the later stages).  Returns dt.
+        -- with nothing but the stage kernels on the device and no host round trip on the critical path.
+
+        The reduced wavespeed lives in one of two device slots.  Stage 0 forms dt in the kernel from the
+        current slot (``dx / amax * cfl``, the driver's IEEE operations: no timestep launch) and zeroes the
+        other slot, into which the last stage folds the wavespeed of the state it produces (no memset, no
+        wavespeed pass); the slots then swap.  Meanwhile the host reads the current slot back on a side
+        stream -- it has been final since the previous step ended, so the read does not wait for stage 0 --
+        and forms the identical dt for its own bookkeeping (time, point-mass positions of the later stages).
+        Same dt, same state, bit for bit, as the two blocking calls.  Returns dt.
         """
         dx = self.mesh.min_spacing() if dx is None else dx
         params = self.rk_parameters()
@@ -602,23 +641,38 @@ class SolverBase:
             self.advance(dt)
             return dt
 
-        floor = self._wavespeed_floor
-        have_fused = all(p.wavespeed_valid for p in self.patches)
-        while True:
-            amax_dev = self._reduce_wavespeed_device(recompute=not have_fused)
-            p0 = self.patches[0]
-            if self._dt_dev is None:
-                with p0.execution_context:
-                    self._dt_dev = p0.xp.zeros(1)
+        p0 = self.patches[0]
+        if self._slots is None:
             with p0.execution_context:
-                fetch = self._start_scalar_fetch(amax_dev)  # read-back on a side stream, not behind stage 0
-                p0.lib.sfhip_timestep[1](float(dx), float(cfl_number), amax_dev, self._dt_dev)
+                self._slots = p0.xp.zeros(2)
+                self._slot_views = (self._slots[0:1], self._slots[1:2])
+        floor = self._wavespeed_floor
+        filtered = self._slot_valid or all(p.wavespeed_valid for p in self.patches)
+        self._dt_dx, self._dt_cfl = float(dx), float(cfl_number)
+        while True:
+            cur, nxt = self._slot_views[self._slot_cur], self._slot_views[1 - self._slot_cur]
+            if not self._slot_valid:
+                amax_dev = self._reduce_wavespeed_device(recompute=not filtered)
+                with p0.execution_context:
+                    cur.copy_(amax_dev)
+            plan = getattr(p0, "plan", None)
+            if plan is not None:
+                # stage 0 itself hands the value over through pinned memory as soon as it starts (no copy, no event)
+                self._host_seq += 1.0
+                seq = self._host_seq
+                fetch = lambda: plan.host_wait(seq)  # noqa: E731
+            else:
+                seq = 0.0
+                with p0.execution_context:
+                    fetch = self._start_scalar_fetch(cur)  # read-back on a side stream, not behind stage 0
             self.new_iteration()
             # dt is not known on the host yet: nothing below may depend on it (stage 0 never does)
-            wrote = self.advance_rk(params[0], float("nan"), 0, len(params), dt_device=self._dt_dev)
+            wrote = self.advance_rk(params[0], float("nan"), 0, len(params), slots=(cur, nxt), host_seq=seq)
             amax = fetch()  # the one device->host sync of the step; stage 0 is still running on the device
-            if have_fused and amax < floor:
-                have_fused = False  # the filtered maximum is only a lower bound: recompute exactly and redo stage 0
+            if filtered and amax < floor:
+                # the filtered maximum is only a lower bound: recompute exactly and redo stage 0
+                filtered = False
+                self._slot_valid = False
                 continue
             break
         self._wavespeed_floor = 0.5 * amax
@@ -626,7 +680,12 @@ class SolverBase:
         for p, wr in zip(self.patches, wrote):
             p.finish_stage(params[0], dt, wr)
         for stage in range(1, len(params)):
-            self.advance_rk(params[stage], dt, stage, len(params))
+            self.advance_rk(params[stage], dt, stage, len(params), slots=(cur, nxt))
+        if self.comm.enabled:
+            with p0.execution_context:
+                self.comm.max_scalar(nxt)  # on the compute stream, behind the last stage; stays on the device
+        self._slot_cur = 1 - self._slot_cur
+        self._slot_valid = True
         return dt
 
     def _start_scalar_fetch(self, scalar):
@@ -637,6 +696,10 @@ class SolverBase:
         """
         if self.backend.mode != "hip":
             return lambda: float(scalar.item())
+        plan = getattr(self.patches[0], "plan", None)  # (the cbdisodg_2d patches have none)
+        if plan is not None:  # pinned word, stream and events owned by the plan: two C calls, no torch bookkeeping
+            plan.fetch_begin(scalar)
+            return plan.fetch_wait
         torch = self._torch()
         if self._fetch_stream is None:
             self._fetch_stream = torch.cuda.Stream()
@@ -673,18 +736,19 @@ class SolverBase:
         return local
 
     def _launch(self, p, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed,
-                dt_device=None):
+                extra=None, on_side_stream=False):
         """One stage-kernel launch on patch `p`, optionally bracketed by HIP events on its stream."""
         floor = self._wavespeed_floor
+        extra = extra or {}
         if self.event_log is None:
             p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor,
-                           dt_device=dt_device)
+                           on_side_stream=on_side_stream, **extra)
             return
         torch = self._torch()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         fire = p.launch_stage(rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed, floor,
-                              defer=True, dt_device=dt_device)
+                              defer=True, on_side_stream=on_side_stream, **extra)
         e0.record()
         fire()
         e1.record()
@@ -743,6 +807,9 @@ class SolverBase:
             with self.patches[0].execution_context:
                 if self._comm_stream is None:
                     self._comm_stream = torch.cuda.Stream()
+                    for p in self.patches:
+                        if getattr(p, "plan", None) is not None:
+                            p.plan.set_side_stream(self._comm_stream)
                 if between is not None:
                     ready = torch.cuda.Event()
                     ready.record()

@@ -115,18 +115,36 @@ class Patch(PatchBase):
             self.lib.sfhip_max_nonneg[self.wavespeeds.numel()](self.wavespeeds, self.wavespeed_max)
 
     def launch_stage(self, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed,
-                     wavespeed_floor=0.0, defer=False, dt_device=None):
+                     wavespeed_floor=0.0, defer=False, on_side_stream=False, amax_device=None, dt_dx=0.0,
+                     dt_cfl=0.0, zero_slot=None, fold_into=None, host_seq=0.0):
+        """One fused stage launch (sfhip_cbdgam_2d_stage); see the cbdiso_2d Patch."""
         m1, m2 = masses
-        fire = self.lib.sfhip_cbdgam_2d_stage[self.shape].bind(
-            *self._extent(), un, rd, wr,
-            *self._head_args(m1, m2), *m1.kernel_args(), *m2.kernel_args(),
-            *self._tail_args(rk_param, dt),
-            2 if un is not None else 0, int(self.first), int(self.last), i_begin, i_end, want_wavespeed,
-            wavespeed_floor, self.wavespeed_max, dt_device,
-        )
+        wmax = self.wavespeed_max if fold_into is None else fold_into
+        if self.plan is not None:
+            fire = self.plan.stage(self, m1, m2, None, None, un, rd, wr, rk_param, dt, i_begin, i_end, want_wavespeed,
+                                   wavespeed_floor, wmax, amax_device, dt_dx, dt_cfl, zero_slot, on_side_stream,
+                                   host_seq)
+        else:
+            assert host_seq == 0.0, "the pinned-memory hand-over is a service of the launch plans"
+            fire = self.lib.sfhip_cbdgam_2d_stage[self.shape].bind(
+                *self._extent(), un, rd, wr,
+                *self._head_args(m1, m2), *m1.kernel_args(), *m2.kernel_args(),
+                *self._tail_args(rk_param, dt),
+                2 if un is not None else 0, int(self.first), int(self.last), i_begin, i_end, want_wavespeed,
+                wavespeed_floor, wmax, None, amax_device, dt_dx, dt_cfl, zero_slot,
+            )
         if defer:
             return fire
         fire()
+
+    def plan_constants(self):
+        """Constant arguments of sfhip_plan_create_cbdgam_2d, in its order (include/sfhip.h)."""
+        ph, o = self.physics, self.options
+        return (*self.shape, *self._extent(), ph.gamma_law_index, self.buffer_surface_density,
+                self.buffer_surface_pressure, ph.buffer_driving_rate, self.buffer_outer_radius,
+                ph.buffer_onset_width, int(ph.buffer_is_enabled), ph.alpha, o.velocity_ceiling,
+                ph.cooling_coefficient, o.mach_ceiling, o.density_floor, o.pressure_floor,
+                int(ph.constant_softening), int(self.first), int(self.last))
 
 
 class Solver(SolverBase):

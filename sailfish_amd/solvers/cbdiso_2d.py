@@ -119,22 +119,42 @@ class Patch(PatchBase):
             self.lib.sfhip_max_nonneg[self.wavespeeds.numel()](self.wavespeeds, self.wavespeed_max)
 
     def launch_stage(self, rk_param, dt, rd, un, wr, masses, next_masses, i_begin, i_end, want_wavespeed,
-                     wavespeed_floor=0.0, defer=False, dt_device=None):
+                     wavespeed_floor=0.0, defer=False, on_side_stream=False, amax_device=None, dt_dx=0.0,
+                     dt_cfl=0.0, zero_slot=None, fold_into=None, host_seq=0.0):
+        """
+        One fused stage launch (sfhip_cbdiso_2d_stage).  `fold_into`: where want_wavespeed folds, default this
+        patch's own scalar; amax_device / dt_dx / dt_cfl / zero_slot: see include/sfhip.h.  On the device the
+        call goes through the patch's launch plan (constants marshalled once), elsewhere through the Library.
+        """
         m1, m2 = masses
         w1, w2 = next_masses
-        fire = self.lib.sfhip_cbdiso_2d_stage[self.shape].bind(
-            *self._extent(), un, rd, wr,
-            *self._buffer_args(m1, m2), *m1.kernel_args(), *m2.kernel_args(),
-            *self._tail_args(rk_param, dt),
-            2 if un is not None else 0, int(self.first), int(self.last), i_begin, i_end, want_wavespeed,
-            wavespeed_floor,
-            w1.position_x, w1.position_y, w1.mass, w1.softening_length,
-            w2.position_x, w2.position_y, w2.mass, w2.softening_length,
-            self.wavespeed_max, dt_device,
-        )
+        wmax = self.wavespeed_max if fold_into is None else fold_into
+        if self.plan is not None:
+            fire = self.plan.stage(self, m1, m2, w1, w2, un, rd, wr, rk_param, dt, i_begin, i_end, want_wavespeed,
+                                   wavespeed_floor, wmax, amax_device, dt_dx, dt_cfl, zero_slot, on_side_stream,
+                                   host_seq)
+        else:
+            assert host_seq == 0.0, "the pinned-memory hand-over is a service of the launch plans"
+            fire = self.lib.sfhip_cbdiso_2d_stage[self.shape].bind(
+                *self._extent(), un, rd, wr,
+                *self._buffer_args(m1, m2), *m1.kernel_args(), *m2.kernel_args(),
+                *self._tail_args(rk_param, dt),
+                2 if un is not None else 0, int(self.first), int(self.last), i_begin, i_end, want_wavespeed,
+                wavespeed_floor,
+                w1.position_x, w1.position_y, w1.mass, w1.softening_length,
+                w2.position_x, w2.position_y, w2.mass, w2.softening_length,
+                wmax, None, amax_device, dt_dx, dt_cfl, zero_slot,
+            )
         if defer:
             return fire
         fire()
+
+    def plan_constants(self):
+        """Constant arguments of sfhip_plan_create_cbdiso_2d, in its order (include/sfhip.h)."""
+        ph, o = self.physics, self.options
+        return (*self.shape, *self._extent(), self.buffer_surface_density, ph.buffer_driving_rate,
+                self.buffer_outer_radius, ph.buffer_onset_width, int(ph.buffer_is_enabled), *self._eos_args(),
+                ph.viscosity_coefficient, o.velocity_ceiling, o.density_floor, int(self.first), int(self.last))
 
 
 class Solver(SolverBase):

@@ -153,6 +153,12 @@ class OracleLibrary:
     def _sfhip_max_nonneg(self, shape, kw, args):
         kw["out"][0] = float(_np(kw["x"]).reshape(-1)[: shape[0]].max())
 
+    @staticmethod
+    def _timestep(kw):
+        """dt_dx / *amax_device * dt_cfl in IEEE doubles, as the stage kernels form it (include/sfhip.h)."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.float64(kw["dt_dx"]) / np.float64(kw["amax_device"][0]) * np.float64(kw["dt_cfl"]))
+
     def _sfhip_timestep(self, shape, kw, args):
         with np.errstate(divide="ignore"):  # amax == 0 gives inf on the device too
             kw["dt_out"][0] = float(np.float64(kw["dx"]) / np.float64(kw["wavespeed_max"][0]) * np.float64(kw["cfl"]))
@@ -171,6 +177,10 @@ class OracleLibrary:
         ref_args[4], ref_args[5], ref_args[6] = cons, rd, out
         if kw["dt_device"] is not None:
             ref_args[36] = float(kw["dt_device"][0])
+        if kw["amax_device"] is not None:
+            ref_args[36] = self._timestep(kw)
+        if kw["zero_slot"] is not None:
+            kw["zero_slot"][0] = 0.0
         self.orc.call("cbdiso_2d_advance_rk", shape, *ref_args)
         i0, i1 = kw["i_begin"] + NG, kw["i_end"] + NG
         _np(kw["primitive_wr"])[i0:i1, NG:-NG] = out[i0:i1, NG:-NG]
@@ -207,6 +217,10 @@ class OracleLibrary:
         ref_args[4], ref_args[5], ref_args[6] = cons, rd, out
         if kw["dt_device"] is not None:
             ref_args[35] = float(kw["dt_device"][0])
+        if kw["amax_device"] is not None:
+            ref_args[35] = self._timestep(kw)
+        if kw["zero_slot"] is not None:
+            kw["zero_slot"][0] = 0.0
         self.orc.call("cbdgam_2d_advance_rk", shape, *ref_args)
         i0, i1 = kw["i_begin"] + NG, kw["i_end"] + NG
         _np(kw["primitive_wr"])[i0:i1, NG:-NG] = out[i0:i1, NG:-NG]

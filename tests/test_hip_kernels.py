@@ -162,7 +162,7 @@ def test_fused_epilogue_keeps_a_nan(hip_lib, orc):
     hip_lib.sfhip_cbdgam_2d_stage[c["shape"]](
         *c["extent"], None, dev(prim), wr, c["gamma"], *c["buffer"], *c["m1"], *c["m2"],
         c["alpha"], 0.0, c["dt"], c["vmax"], c["cooling"], c["mach_ceiling"], c["dfloor"], c["pfloor"],
-        c["constant_softening"], 0, 1, 1, 0, c["shape"][0], 2, 0.5, wmax, None)
+        c["constant_softening"], 0, 1, 1, 0, c["shape"][0], 2, 0.5, wmax, None, None, 0.0, 0.0, None)
     assert np.isnan(host(wr)[2 + 37, 2 + 101]).any()
     assert np.isnan(float(wmax.item()))
 
@@ -233,7 +233,8 @@ def test_iso_fused_stage_equals_reference_sequence(hip_lib, orc, a, shape, floor
             *c["buffer"], *c["m1"], *c["m2"], *c["eos"], c["nu"], c["a"],
             c["dt"] if k == 0 else float("nan"), c["vmax"], c["dfloor"],
             2, 1, 1, i0, i1, 2 if k == 0 else 1, floor,
-            w1[0], w1[1], w1[4], w1[5], w2[0], w2[1], w2[4], w2[5], wmax, None if k == 0 else d_dt)
+            w1[0], w1[1], w1[4], w1[5], w2[0], w2[1], w2[4], w2[5], wmax, None if k == 0 else d_dt,
+            None, 0.0, 0.0, None)
     got = host(d_pn)
     err = cases.zone_relative_error(got, expect)
     assert err <= ADVANCE_TOL, err

@@ -215,3 +215,26 @@ def test_gam_decomposition_invariance_2048():
         runs.append((dts, s.solution))
     assert runs[0][0] == runs[1][0]
     assert np.array_equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize("model,num_patches,rk_order", [({}, 1, 2), ({}, 3, 3), (dict(eos="gamma-law"), 2, 2)])
+def test_launch_plans_equal_library_calls(model, num_patches, rk_order, monkeypatch):
+    """The solvers launch the fused stage through a plan (constants marshalled once, include/sfhip.h "launch
+    plans"); SFHIP_NO_PLANS=1 sends the same launches through Library's kernel[shape](*args).  Same C function
+    underneath: dt sequence and state agree bit for bit, for step() and for timestep() + advance()."""
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(96)
+    options = dict(rk_order=rk_order) if rk_order != 2 else {}
+    runs = []
+    for no_plans in ("", "1"):
+        monkeypatch.setenv("SFHIP_NO_PLANS", no_plans)
+        s = make_solver(setup.solver, setup.physics, options, setup=setup, mesh=mesh, time=0.0,
+                        num_patches=num_patches, mode="hip")
+        assert (s.patches[0].plan is None) == bool(no_plans)
+        dts = [s.step(s.recommended_cfl) for _ in range(4)]
+        dts.append(timestep(mesh, s, s.recommended_cfl))
+        s.advance(dts[-1])
+        dts += [s.step(s.recommended_cfl) for _ in range(2)]
+        runs.append((dts, s.time, s.solution))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert np.array_equal(runs[0][2], runs[1][2])

@@ -73,7 +73,10 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     for name in list(api) + ["sfhip_set_device", "sfhip_device_count", "sfhip_set_stream", "sfhip_synchronize",
-                             "sfhip_last_error", "sfhip_selftest_lane_shift"]:
+                             "sfhip_last_error", "sfhip_selftest_lane_shift",
+                             "sfhip_plan_create_cbdiso_2d", "sfhip_plan_create_cbdgam_2d", "sfhip_plan_set_side_stream",
+                             "sfhip_plan_destroy", "sfhip_plan_stage", "sfhip_plan_fetch_begin",
+                             "sfhip_plan_fetch_wait", "sfhip_plan_host_wait"]:
         assert name in exported, name
 
 
