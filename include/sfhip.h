@@ -515,6 +515,48 @@ SFHIP_API int sfhip_cbdiso_2d_reductions(
     double *sums) // :: $.numel() >= 2 * num_diagnostics
 ;
 
+/* No counterpart in the reference.  For callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc) and so cannot bring the
+ * workspace either: sfhip_cbdiso_2d_reductions with its block partials in a device array
+ * built into the library (128 KiB per GPU, held until the process ends) instead of a
+ * caller-provided workspace.  Same kernels, same launch geometry, bit-identical sums.
+ * Calls no hipMalloc / hipFree or other allocating routine.  Limit: the launch must fit
+ * 1024 blocks of partials, i.e. nj <= 262 144 (any ni); larger patches are refused with
+ * -1 and a message.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (different streams or threads) race; calls on one stream are ordered. */
+SFHIP_API int sfhip_cbdiso_2d_reductions_noalloc(
+    int ni,
+    int nj,
+    double patch_xl, // mesh
+    double patch_xr,
+    double patch_yl,
+    double patch_yr,
+    double x1,
+    double y1,
+    double vx1,
+    double vy1,
+    double mass1,
+    double softening_length1,
+    double sink_rate1,
+    double sink_radius1,
+    int sink_model1,
+    double x2,
+    double y2,
+    double vx2,
+    double vy2,
+    double mass2,
+    double softening_length2,
+    double sink_rate2,
+    double sink_radius2,
+    int sink_model2,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *xcoord, // :: $.numel() >= ni
+    double *ycoord, // :: $.numel() >= nj
+    int num_diagnostics, // :: 1 <= $ <= 8
+    double *spec, // :: $.numel() >= 8 * num_diagnostics
+    double *sums) // :: $.numel() >= 2 * num_diagnostics
+;
+
 /* As above for cbdgam_2d (cbdgam_2d.py:341-443); quantity codes 0..3 are the rates
  * of the four conserved fields. */
 SFHIP_API int sfhip_cbdgam_2d_reductions(

@@ -979,6 +979,78 @@ int sfhip_cbdgam_2d_reductions(
 } // extern "C"
 
 // ---------------------------------------------------------------------------
+// The entry point that allocates nothing (no counterpart in the reference; for callers that cannot call
+// hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it -- nor bring a
+// workspace).  sfhip_cbdiso_2d_reductions with its block partials in a file-scope device array instead of a
+// caller-provided workspace.  Limit: the launch may have at most NOALLOC_MAX_BLOCKS blocks (any ni; nj up to
+// 262 144), 128 KiB of device memory per GPU, held until the process ends.
+//
+// `noalloc_scratch` is a host-side stand-in in host code, not a device address: the address of each GPU's own
+// copy is looked up once per device with hipGetSymbolAddress (with that device current) and kept; kernels,
+// and anything else on the host that needs the memory, get that pointer.  Every call on a GPU shares that
+// GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not.
+// Nothing has to start at zero -- every block writes all of its slots before the second kernel reads them --
+// so the array keeps the previous call's contents and is not cleared.
+// ---------------------------------------------------------------------------
+constexpr int NOALLOC_MAX_BLOCKS = 1024;
+static __device__ __align__(256) double noalloc_scratch[NOALLOC_MAX_BLOCKS * sf::RED_SLOTS];
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+double *g_noalloc_ptr[NOALLOC_MAX_DEVICES]; // per device: that GPU's noalloc_scratch
+std::mutex g_noalloc_mutex;
+
+int noalloc_scratch_ptr(double **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(-1, "sfhip_cbdiso_2d_reductions_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(noalloc_scratch)); // the current device's copy
+        if (e != hipSuccess || !ptr) {
+            snprintf(t_error, sizeof(t_error), "hipGetSymbolAddress(noalloc_scratch) on device %d: %s", dev,
+                     e != hipSuccess ? hipGetErrorString(e) : "null address");
+            return e != hipSuccess ? (int)e : -1;
+        }
+        g_noalloc_ptr[dev] = (double *)ptr;
+    }
+    *out = g_noalloc_ptr[dev];
+    return 0;
+}
+} // namespace
+
+extern "C" int sfhip_cbdiso_2d_reductions_noalloc(
+    int ni, int nj, double patch_xl, double patch_xr, double patch_yl, double patch_yr,
+    double x1, double y1, double vx1, double vy1, double mass1, double softening_length1,
+    double sink_rate1, double sink_radius1, int sink_model1,
+    double x2, double y2, double vx2, double vy2, double mass2, double softening_length2,
+    double sink_rate2, double sink_radius2, int sink_model2,
+    double *primitive, double *xcoord, double *ycoord, int num_diagnostics, double *spec, double *sums)
+{
+    const int need = reductions_workspace_len(ni, nj);
+    if (need < 1) return fail(-1, "sfhip_cbdiso_2d_reductions_noalloc: ni, nj must be >= 1");
+    if (need > NOALLOC_MAX_BLOCKS * sf::RED_SLOTS) {
+        snprintf(t_error, sizeof(t_error),
+                 "sfhip_cbdiso_2d_reductions_noalloc: a %d x %d patch needs %d doubles of block partials, the built-in "
+                 "scratch array holds %d (nj <= 262144); use sfhip_cbdiso_2d_reductions with a workspace",
+                 ni, nj, need, NOALLOC_MAX_BLOCKS * sf::RED_SLOTS);
+        return -1;
+    }
+    double *scratch = nullptr;
+    int rc = noalloc_scratch_ptr(&scratch);
+    if (rc) return rc;
+    return reductions_impl<3>("sfhip_cbdiso_2d_reductions_noalloc: bad arguments", ni, nj, patch_xl, patch_xr, patch_yl,
+        patch_yr,
+        make_mass(x1, y1, vx1, vy1, mass1, softening_length1, sink_rate1, sink_radius1, sink_model1),
+        make_mass(x2, y2, vx2, vy2, mass2, softening_length2, sink_rate2, sink_radius2, sink_model2),
+        1, 0.0, primitive, xcoord, ycoord, num_diagnostics, spec, NOALLOC_MAX_BLOCKS * sf::RED_SLOTS, scratch, sums);
+}
+
+
+// ---------------------------------------------------------------------------
 // srhd_2d -- reference-named entry points
 // ---------------------------------------------------------------------------
 namespace {
