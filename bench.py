@@ -3,29 +3,40 @@
 bench.py -- zone-updates/sec of the cbdiso_2d hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-A "step" is what the reference's driver does per iteration (driver.py:508-511):
-dt from the max-wavespeed reduction, then one full RK2 ``solver.advance(dt)``.
-Workload: BASELINE.json configs[1], the circumbinary-disk setup at 4096^2 fp64
-on one MI355X (single patch).  For N > 1 the per-GPU work is held at 4096^2
-zones (weak scaling): the square mesh grows to 4096*sqrt(N) per side and is cut
-into N slab patches, one per rank, with halo slabs and the dt MAX all-reduce on
-RCCL.  Initial data are the setup's analytic disk (no RNG, no files): resident
-in HBM before the clock starts.
+works from a bare shell for any N: for N > 1 (and no torch.distributed environment) it starts
+``python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`` as a child process --
+before anything here has touched the GPU -- relays its output and exits with its code.  Launched under
+torch.distributed.run directly (the round driver does that) it reads RANK / LOCAL_RANK / WORLD_SIZE from the
+environment.  Rank 0 prints ONE JSON line.
 
-Output (rank 0): ONE JSON line with the driver's contract fields plus
-  roofline     -- the stage kernel's achieved algorithmic GB/s against HBM peak,
-                  launch durations measured with HIP events inside the timed region
-  cpu_baseline -- the reference's own C/OpenMP kernels (oracle/_ref, built from
-                  /root/reference by oracle/build_ref.py) or, where absent, our
-                  C port (oracle/sf_oracle.c), driven in the reference's order
-                  on a bounded sample of the same workload (N = 1, rank 0 only).
+A "step" is what the reference's driver does per iteration (driver.py:508-511): dt from the max-wavespeed
+reduction, then one full RK2 ``solver.advance(dt)``.
+
+Workloads
+  N = 1   BASELINE.json configs[1]: circumbinary-disk 4096^2 fp64, single patch on one MI355X.
+  N > 1   headline (``value``): WEAK scaling at 4096^2 zones per GPU -- a square mesh of 4096*sqrt(N) per side
+          cut into N slab patches, one per rank, halo slabs and the dt MAX all-reduce on RCCL.
+          Also measured in the same run and reported beside it (never as ``value``):
+            "strong_scaling"  BASELINE.json's metric line, the 4096^2 mesh cut into N slabs;
+            "config2"         at N = 8: BASELINE.json configs[2], 16384^2 (2048 x 16384 per rank).
+Initial data are the setup's analytic disk (no RNG, no files), resident in HBM before the clock starts.
+
+Output fields beyond the driver's contract
+  roofline       the stage kernel's algorithmic GB/s against the HBM peak; launch durations from HIP events
+                 around the launches of every 4th timed step, minus the calibrated cost of an empty bracket
+  roofline_valu  what actually binds: the kernel's fp64 VALU instruction stream (count per launch from the
+                 committed PMC pass, profiles/valu.json) against the issue rate of 1024 SIMDs
+  cpu_baseline   the reference's own C/OpenMP kernels (oracle/_ref, built from /root/reference by
+                 oracle/build_ref.py) or, where absent, our C port (oracle/sf_oracle.c), driven in the
+                 reference's order on a bounded sample of the same workload (N = 1, rank 0 only).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +48,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS = 1024           # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INSTRUCTION = 4.0  # a wave64 fp64 instruction occupies its SIMD's 16 lanes for 4 cycles
 # Algorithmic bytes per zone: a stage reads p and writes p' (NCONS fp64 each); a stage
 # with a != 0 also reads the u^n source at the zone centre.  RK2 zone-update = one of each.
 NCONS = {"iso": 3, "gam": 4, "srhd": 4, "dg": 3}
@@ -63,25 +76,42 @@ def parse_args():
     ap.add_argument("--sync-dt", action="store_true", help="dt = dx/maximum_wavespeed()*cfl; advance(dt) as two blocking calls")
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--event-stride", type=int, default=4,
-                    help="bracket the kernel launches of every Nth timed step with HIP events (the brackets cost "
-                         "~3.5 us per launch: 2.4 %% of the step at stride 1, measured)")
+                    help="bracket the kernel launches of every Nth timed step with HIP events")
     ap.add_argument("--strong", action="store_true",
-                    help="hold the MESH at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
+                    help="headline = the MESH held at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: measure the headline workload only")
+    ap.add_argument("--base-resolution", type=int, default=4096,
+                    help="side of the one-GPU mesh the scaling series are built from (4096: BASELINE.json's; smaller "
+                         "values only to rehearse the N > 1 flow quickly)")
+    ap.add_argument("--transport", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: all ranks share cuda:0 and exchange through gloo (rehearsal of the N > 1 flow on a "
+                         "one-GPU box; RCCL refuses two ranks on one device)")
     return ap.parse_args()
 
 
-def recorded_traffic(solver, resolution, world):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile.sh (profiles/traffic.json:
-    2 x FETCH_SIZE + WRITE_SIZE, in KiB, as the MI355X guide prescribes), or None for an unprofiled configuration."""
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(tpath):
+def launch_ranks(args):
+    """N > 1 from a bare shell: one child process per GPU through torch.distributed.run (nothing here has
+    initialised the GPU: no torch import has happened in this process)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd).returncode
+
+
+def recorded(table, solver, resolution, world):
+    """A per-launch figure of the dominant kernel from the committed PMC passes (tools/profile.sh ->
+    tools/collect_profile.py -> profiles/<table>.json), or None for a configuration that was not profiled."""
+    path = os.path.join(ROOT, "profiles", table + ".json")
+    if not os.path.exists(path):
         return None
-    with open(tpath) as f:
+    with open(path) as f:
         return json.load(f).get(f"{solver}_{resolution}_{world}")
 
 
-def default_resolution(gpus):
-    n = 4096.0 * math.sqrt(gpus)
+def default_resolution(gpus, base=4096):
+    n = base * math.sqrt(gpus)
     return int(n // 8) * 8
 
 
@@ -143,46 +173,86 @@ def cpu_baseline(setup_name, setup_kwargs, resolution, target_seconds):
     )
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
+class Ranks:
+    """The process's place in the job and the two collectives the bench itself needs."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    def __init__(self, args):
+        import torch
 
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.transport = args.transport
+        if self.transport == "gloo":
+            os.environ["LOCAL_RANK"] = "0"  # every rank on cuda:0 (the solvers read LOCAL_RANK too)
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self.dist = dist
+            if self.transport == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        if self.dist is None:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64,
+                              device="cpu" if self.transport == "gloo" else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def bracket_overhead_ms(torch, samples=40):
+    """What a pair of HIP events around NOTHING measures on the launch stream: the part of every bracket that
+    is not the kernel (the command processor's event handling)."""
+    torch.cuda.synchronize()
+    pairs = []
+    for _ in range(samples):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    times = sorted(a.elapsed_time(b) for a, b in pairs)
+    return times[len(times) // 2]
+
+
+def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
+    """Build the workload, run `warmup` untimed and `steps` timed steps between fences; MAX seconds over ranks."""
+    torch = ranks.torch
     from sailfish_amd.driver import timestep
     from sailfish_amd.setups import make_setup
     from sailfish_amd.solvers import make_solver
 
-    if args.solver == "srhd":
+    if solver_kind == "srhd":
         # BASELINE.json configs[4]: the reference's own srhd_2d problem, a relativistic shell in a homologous
         # envelope on an expanding log-spherical mesh; 4800 zones per decade = 4800 x 3273 zones on one GPU
         setup_name, setup_kwargs = "envelope-shock", dict(polar_extent=0.5)
-        resolution = args.resolution or int(4800 * math.sqrt(args.gpus))
-        extra = dict(fused=not args.unfused)
-    elif args.solver == "dg":
+    elif solver_kind == "dg":
         # SURVEY.md 8(f) rank 4: the reference's DG-capable setup; 2048^2 zones x 18 weights on one GPU
         setup_name, setup_kwargs = "kitp-code-comparison", dict(use_dg=True)
-        resolution = args.resolution or (2048 if args.strong else int(2048 * math.sqrt(args.gpus)) // 8 * 8)
-        extra = dict(fused=not args.unfused)
     else:
         setup_name = "circumbinary-disk"
-        resolution = args.resolution or (4096 if args.strong else default_resolution(args.gpus))
-        setup_kwargs = dict(eos="isothermal" if args.solver == "iso" else "gamma-law")
-        extra = dict(fused=not args.unfused)
+        setup_kwargs = dict(eos="isothermal" if solver_kind == "iso" else "gamma-law")
     setup = make_setup(setup_name, **setup_kwargs)
     mesh = setup.mesh(resolution)
     solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=setup.start_time,
-                         num_patches=world, mode="hip", **extra)
+                         num_patches=ranks.world, mode="hip", fused=not args.unfused)
     cfl = solver.recommended_cfl
 
     def step():
@@ -190,130 +260,198 @@ def main():
             dt = timestep(mesh, solver, cfl)  # the reference driver's literal two calls
             solver.advance(dt)
         else:
-            solver.step(cfl)  # same dt and same work; the 8-byte wavespeed read-back overlaps stage 1
+            solver.step(cfl)  # same dt and same work; no host round trip on the critical path
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    use_events = not args.no_events and not args.unfused
     event_log = [] if use_events else None
     stride = max(1, args.event_stride)
-    fence()
+    ranks.fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         # launch durations are sampled inside the timed region: the launches of every `stride`-th step
         solver.event_log = event_log if k % stride == 0 else None
         step()
-    solver.event_log = event_log
-    fence()
-    seconds = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seconds = float(t.item())
+    ranks.fence()
+    seconds = ranks.max_over_ranks(time.perf_counter() - t0)
+    solver.event_log = None
+    result = dict(resolution=resolution, setup=setup, setup_name=setup_name, setup_kwargs=setup_kwargs, mesh=mesh, seconds=seconds,
+                  steps=steps, zones=mesh.num_total_zones, mzps=mesh.num_total_zones * steps / seconds * 1e-6,
+                  ms_per_step=seconds / steps * 1e3, event_log=event_log, stride=stride,
+                  patch_shape=tuple(solver.patches[0].shape))
+    if use_events and event_log:
+        result["bracket_overhead_ms"] = bracket_overhead_ms(torch)
+    del solver
+    torch.cuda.empty_cache()
+    return result
 
-    zones = mesh.num_total_zones
-    mzps = zones * args.steps / seconds * 1e-6
-    BYTES_STAGE_NO_UN = 2 * 8.0 * NCONS[args.solver]
-    BYTES_STAGE_UN = 3 * 8.0 * NCONS[args.solver]
-    BYTES_PER_ZONE_UPDATE = BYTES_STAGE_NO_UN + BYTES_STAGE_UN
-    if args.solver == "srhd":
-        BYTES_PER_ZONE_UPDATE = SRHD_BYTES_PER_ZONE_UPDATE
-    if args.solver == "dg":
-        BYTES_PER_ZONE_UPDATE = DG_BYTES_PER_ZONE_UPDATE
 
-    roofline = None
-    kernel_ms = None
-    if use_events and solver.event_log and args.solver in ("dg", "srhd"):
+def roofline_of(args, run, world):
+    """roofline / roofline_valu / kernel_ms objects from the event brackets of a measured run (or Nones)."""
+    log = run["event_log"]
+    if not log:
+        return None, None, None
+    solver = run["setup"].solver
+    resolution = run["resolution"]
+    over = run["bracket_overhead_ms"]
+    ncons = NCONS[args.solver]
+    bytes_no_un, bytes_un = 2 * 8.0 * ncons, 3 * 8.0 * ncons
+    per_kernel = {}
+    for e in log:
+        ms = max(e["start"].elapsed_time(e["stop"]) - over, 0.0)
+        if "kernel" in e:  # srhd / dg logs name their kernels and bytes
+            name, alg = e["kernel"], e["zones"] * e["bytes_per_zone"]
+        else:
+            name = "stage_un" if e["reads_un"] else "stage_a0"
+            alg = e["zones"] * (bytes_un if e["reads_un"] else bytes_no_un)
+        k = per_kernel.setdefault(name, [0.0, 0, 0.0])
+        k[0] += ms
+        k[1] += 1
+        k[2] += alg
+    if args.solver in ("dg", "srhd"):
         dominant = "dg_advance_kernel" if args.solver == "dg" else "srhd_march_kernel"
-        per_kernel = {}
-        for e in solver.event_log:
-            k = per_kernel.setdefault(e["kernel"], [0.0, 0, 0.0])
-            k[0] += e["start"].elapsed_time(e["stop"])
-            k[1] += 1
-            k[2] += e["zones"] * e["bytes_per_zone"]
         ms, launches, alg_bytes = per_kernel[dominant]
-        achieved = alg_bytes / (ms * 1e-3) / 1e9
-        roofline = dict(
-            bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=recorded_traffic(setup.solver, resolution, world),
-            kernel="sf::" + dominant, launches=launches,
-            avg_launch_ms=round(ms / launches, 4), algorithmic_bytes_per_launch=round(alg_bytes / launches),
-            note="fp64 VALU-bound (IEEE division and square roots kept for bit-exact results), not HBM-bound: "
-                 "see DESIGN.md",
+        kernel = "sf::" + dominant
+    else:
+        ms = sum(v[0] for v in per_kernel.values())
+        launches = sum(v[1] for v in per_kernel.values())
+        alg_bytes = sum(v[2] for v in per_kernel.values())
+        kernel = "sf::iso_stage_kernel" if args.solver == "iso" else "sf::gam_stage_kernel"
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic = recorded("traffic", solver, resolution, world)
+    roofline = dict(
+        bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+        kernel=kernel, launches=launches, avg_launch_ms=round(ms / launches, 4),
+        algorithmic_bytes_per_launch=round(alg_bytes / launches),
+        binding="fp64 VALU issue, not HBM: see roofline_valu and DESIGN.md section 5",
+        note=f"launch durations: HIP events around every launch of every {run['stride']}. timed step "
+             f"({len(log)} launches inside the timed region), minus the median of 40 empty brackets "
+             f"({over * 1e3:.1f} us) measured on the same stream right after the timed region; a bracketed launch "
+             "runs alone (the events keep it from overlapping its neighbours' ramp-up and drain), so the two "
+             "stages' durations can add up to slightly more than ms_per_step",
+    )
+    if traffic is None:
+        roofline["traffic_note"] = (f"no PMC pass was recorded for {solver} at {resolution}^2 on {world} GPU(s): "
+                                    "profiles/traffic.json holds the profiled shapes")
+    valu = None
+    insts = recorded("valu", solver, resolution, world)
+    if insts:
+        clock_ghz = insts.get("clock_ghz", 2.1)
+        count = insts["insts_per_launch"]  # SQ_INSTS_VALU per launch, averaged over the step's launches
+        rate = count / (ms / launches * 1e-3)
+        peak = SIMDS * clock_ghz * 1e9 / VALU_CYCLES_PER_INSTRUCTION
+        valu = dict(
+            bound="valu", achieved=round(rate / 1e9, 1), peak=round(peak / 1e9, 1), unit="G wave-instructions/s",
+            frac=round(rate / peak, 4), insts_per_launch=count, cycles_per_instruction=insts.get("cycles_per_inst"),
+            clock_ghz=clock_ghz,
+            note="SQ_INSTS_VALU per launch from the committed PMC pass (profiles/valu.json) / this run's launch "
+                 "duration, against 1024 SIMDs x clock / 4 cycles per wave64 fp64 instruction; the clock is the "
+                 "one measured under this kernel in that pass (GRBM_GUI_ACTIVE / wall)",
         )
-        kernel_ms = {name + "_ms": round(v[0] / v[1], 4) for name, v in per_kernel.items()}
-    elif use_events and solver.event_log:
-        alg_bytes = 0.0
-        dur_ms = 0.0
-        per_kind = {False: [0.0, 0], True: [0.0, 0]}
-        for e in solver.event_log:
-            ms = e["start"].elapsed_time(e["stop"])
-            dur_ms += ms
-            alg_bytes += e["zones"] * (BYTES_STAGE_UN if e["reads_un"] else BYTES_STAGE_NO_UN)
-            per_kind[e["reads_un"]][0] += ms
-            per_kind[e["reads_un"]][1] += 1
-        achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
-        traffic = recorded_traffic(setup.solver, resolution, world)
-        roofline = dict(
-            bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-            kernel="sf::iso_stage_kernel" if args.solver == "iso" else "sf::gam_stage_kernel",
-            launches=len(solver.event_log),
-            avg_launch_ms=round(dur_ms / len(solver.event_log), 4),
-            algorithmic_bytes_per_launch=round(alg_bytes / len(solver.event_log)),
-            note=f"launch durations from HIP events around every launch of every {stride}. timed step "
-                 f"({len(solver.event_log)} launches inside the timed region)",
-        )
-        kernel_ms = {
-            "stage_a0_ms": round(per_kind[False][0] / max(per_kind[False][1], 1), 4),
-            "stage_un_ms": round(per_kind[True][0] / max(per_kind[True][1], 1), 4),
-        }
+    kernel_ms = {name + "_ms": round(v[0] / v[1], 4) for name, v in per_kernel.items()}
+    return roofline, valu, kernel_ms
+
+
+def summary(run, world, bytes_per_update):
+    return dict(
+        workload=f"{run['setup'].solver} {run['setup_name']} {run['mesh'].shape[0]}x{run['mesh'].shape[1]} fp64, RK2, "
+                 f"{world} slab patch(es) of {run['patch_shape'][0]}x{run['patch_shape'][1]}, one per GPU",
+        value=round(run["mzps"], 2), unit="Mzps", ms_per_step=round(run["ms_per_step"], 4), steps=run["steps"],
+        hbm_roofline_frac_whole_step=round(run["mzps"] * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
+    )
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
+    ranks = Ranks(args)
+    world = ranks.world
+    args.gpus = world
+
+    if args.solver == "srhd":
+        resolution = args.resolution or int(4800 * math.sqrt(world))
+    elif args.solver == "dg":
+        resolution = args.resolution or (2048 if args.strong else int(2048 * math.sqrt(world)) // 8 * 8)
+    else:
+        base = args.base_resolution
+        resolution = args.resolution or (base if args.strong else default_resolution(world, base))
+    strong = (args.strong or args.resolution is not None) and world > 1
+
+    use_events = not args.no_events and not args.unfused
+    head = measure(args, ranks, args.solver, resolution, args.steps, args.warmup, use_events)
+    bytes_per_update = 5 * 8.0 * NCONS[args.solver]
+    if args.solver == "srhd":
+        bytes_per_update = SRHD_BYTES_PER_ZONE_UPDATE
+    if args.solver == "dg":
+        bytes_per_update = DG_BYTES_PER_ZONE_UPDATE
+    roofline, valu, kernel_ms = roofline_of(args, head, world)
+
+    # N > 1: the other scaling series, measured in the same job (never `value`)
+    extras = {}
+    if world > 1 and args.solver == "iso" and not args.no_extras and args.resolution is None:
+        plans = {}
+        if not args.strong:
+            plans["strong_scaling"] = base          # BASELINE.json's metric: the 4096^2 mesh over N GPUs
+        else:
+            plans["weak_scaling"] = default_resolution(world, base)
+        if world == 8:
+            plans["config2"] = 4 * base             # BASELINE.json configs[2]: 16384^2, 2048 x 16384 per rank
+        for name, n in plans.items():
+            try:
+                run = measure(args, ranks, "iso", n, args.steps, min(args.warmup, 5), False)
+                extras[name] = summary(run, world, bytes_per_update)
+            except Exception as exc:  # an extra is a report, never a reason to lose the headline
+                extras[name] = dict(failed=repr(exc))
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if ranks.rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(setup_name, setup_kwargs, resolution, args.cpu_seconds)
+            cpu = cpu_baseline(head["setup_name"], head["setup_kwargs"], resolution, args.cpu_seconds)
         except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
             cpu = dict(value=None, unit="Mzps", cores=0, kind="port", sample=f"failed: {exc!r}")
 
-    if rank == 0:
-        bytes_per_update = BYTES_PER_ZONE_UPDATE
+    if ranks.rank == 0:
+        setup, mesh = head["setup"], head["mesh"]
         line = {
             "metric": f"zone-updates/sec (Mzps) fp64, {setup.solver}",
-            "value": round(mzps, 2),
+            "value": round(head["mzps"], 2),
             "unit": "Mzps",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(seconds / args.steps * 1e3, 4),
+            "ms_per_step": round(head["ms_per_step"], 4),
             "higher_is_better": True,
-            "scaling": "strong" if (args.strong or args.resolution) and world > 1 else "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{setup.solver} {setup_name} {mesh.shape[0]}x{mesh.shape[1]} fp64, RK2, "
-                            f"{world} slab patch(es), one per GPU; dt recomputed every step",
-                "zones": zones,
-                "zones_per_gpu": zones // world,
+                "workload": f"{setup.solver} {head['setup_name']} {mesh.shape[0]}x{mesh.shape[1]} fp64, RK2, "
+                            f"{world} slab patch(es) of {head['patch_shape'][0]}x{head['patch_shape'][1]}, one per "
+                            f"GPU; dt recomputed every step"
+                            + ("" if world == 1 else
+                               ("; headline = strong scaling of the 4096^2 mesh" if strong else
+                                "; headline = weak scaling at 4096^2 zones per GPU (strong scaling and config 2 "
+                                "are reported beside it)")),
+                "zones": head["zones"],
+                "zones_per_gpu": head["zones"] // world,
                 "path": "reference-order kernels" if args.unfused else "fused stage kernels",
+                "transport": None if world == 1 else ("RCCL" if args.transport == "nccl" else "gloo, all ranks on cuda:0"),
             },
-            "hbm_roofline_frac_whole_step": round(mzps * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
+            "hbm_roofline_frac_whole_step": round(head["mzps"] * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline,
+            "roofline_valu": valu,
             "cpu_baseline": cpu,
         }
         if kernel_ms:
             line["kernel_ms"] = kernel_ms
+        line.update(extras)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,78 @@
+"""
+bench.py from a bare shell: `--gpus 2` starts its own ranks (torch.distributed.run as a child process, before
+anything has touched the GPU) and rank 0 prints the one JSON line.  `--transport gloo` puts both ranks on the
+test box's single GPU -- RCCL refuses two ranks on one device -- so the launcher and the two-rank flow of the
+bench (slab patches, halo exchange on the side stream, device-side dt behind the MAX all-reduce, fences, MAX of
+the ranks' clocks) are exercised here; the round driver's N > 1 runs use RCCL.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags, timeout=280):
+    env = dict(os.environ)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_from_a_bare_shell():
+    line = run_bench("--gpus", "2", "--transport", "gloo", "--steps", "2", "--warmup", "1", "--resolution", "512",
+                     "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["unit"] == "Mzps" and line["value"] > 0.0
+    assert line["config"]["zones"] == 512 * 512 and line["config"]["zones_per_gpu"] == 512 * 256
+    assert "256x512" in line["config"]["workload"] and line["scaling"] == "strong"
+    assert line["roofline"]["frac"] > 0.0 and line["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_reports_both_scaling_series():
+    """Without --resolution the N > 1 line carries the weak-scaling headline and the strong-scaling run beside it
+    (two workloads built and measured in one job); a small base mesh keeps the gloo rehearsal quick."""
+    line = run_bench("--gpus", "2", "--transport", "gloo", "--steps", "2", "--warmup", "1", "--base-resolution", "256",
+                     "--no-cpu-baseline")
+    assert line["scaling"] == "weak" and line["config"]["zones"] == 360 * 360  # 256 * sqrt(2), multiple of 8
+    strong = line["strong_scaling"]
+    assert strong["value"] > 0.0 and "256x256" in strong["workload"] and "128x256" in strong["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_the_contract_fields():
+    line = run_bench("--steps", "4", "--warmup", "2", "--resolution", "512", "--cpu-seconds", "1")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["dtype"] == "f64" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # kernel time sampled inside the timed region cannot exceed the step it is part of by more than sampling noise
+    assert sum(line["kernel_ms"].values()) <= 1.25 * line["ms_per_step"]
+    assert line["cpu_baseline"]["value"] > 0.0 and line["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_launcher_builds_the_torchrun_command(monkeypatch):
+    """No GPU needed: the parent only composes the child's command line (and must not import torch to do so)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    calls = []
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: calls.append(cmd) or type("R", (), {"returncode": 7})())
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    args = bench.parse_args()
+    assert bench.launch_ranks(args) == 7
+    cmd = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
