@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--strong", action="store_true",
                     help="headline = the MESH held at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: measure the headline workload only")
+    ap.add_argument("--ramp-seconds", type=float, default=0.5,
+                    help="untimed steps of the same workload run for this long BEFORE the W warmup steps, so that "
+                         "the GPU's clocks have left their idle state when the (short) timed region starts; the "
+                         "number of steps this took is reported as config.clock_ramp_steps")
     ap.add_argument("--base-resolution", type=int, default=4096,
                     help="side of the one-GPU mesh the scaling series are built from (4096: BASELINE.json's; smaller "
                          "values only to rehearse the N > 1 flow quickly)")
@@ -262,6 +266,22 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
         else:
             solver.step(cfl)  # same dt and same work; no host round trip on the critical path
 
+    ramp_steps = 0
+    if args.ramp_seconds > 0.0:
+        # The device leaves its idle clocks only after some tens of milliseconds of load: with the round driver's
+        # 5 warmup + 20 timed steps (14 ms of work) the timed region would otherwise sit on the ramp itself
+        # (0.69 against 0.57 ms per step, measured).  Untimed steps of the same workload for about ramp_seconds
+        # come first; every rank takes the same number of them (there are collectives inside a step).
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        per_step = max((time.perf_counter() - t0) / 5, 1e-5)
+        ramp_steps = int(ranks.max_over_ranks(float(min(5000, int(args.ramp_seconds / per_step)))))
+        for _ in range(ramp_steps):
+            step()
+        torch.cuda.synchronize()
+        ramp_steps += 5
     for _ in range(warmup):
         step()
     event_log = [] if use_events else None
@@ -277,7 +297,7 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
     solver.event_log = None
     result = dict(resolution=resolution, setup=setup, setup_name=setup_name, setup_kwargs=setup_kwargs, mesh=mesh, seconds=seconds,
                   steps=steps, zones=mesh.num_total_zones, mzps=mesh.num_total_zones * steps / seconds * 1e-6,
-                  ms_per_step=seconds / steps * 1e3, event_log=event_log, stride=stride,
+                  ms_per_step=seconds / steps * 1e3, event_log=event_log, stride=stride, ramp_steps=ramp_steps,
                   patch_shape=tuple(solver.patches[0].shape))
     if use_events and event_log:
         result["bracket_overhead_ms"] = bracket_overhead_ms(torch)
@@ -439,6 +459,7 @@ def main():
                 "zones": head["zones"],
                 "zones_per_gpu": head["zones"] // world,
                 "path": "reference-order kernels" if args.unfused else "fused stage kernels",
+                "clock_ramp_steps": head["ramp_steps"],
                 "transport": None if world == 1 else ("RCCL" if args.transport == "nccl" else "gloo, all ranks on cuda:0"),
             },
             "hbm_roofline_frac_whole_step": round(head["mzps"] * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),

@@ -44,6 +44,9 @@ __device__ __forceinline__ double from_lane_above(double x) // value held by lan
     return __hiloint2double(hi, lo);
 }
 
+// (The same moves through the LDS crossbar -- ds_bpermute_b32, not a VALU instruction -- were measured: 2-3 %
+// slower; the stage kernels do not have the lgkm latency to spare at three waves per SIMD.)
+
 // A wave-uniform double moved to scalar registers: a plain operand of vector instructions from then on.
 __device__ __forceinline__ double uniform_value(double x)
 {
@@ -113,7 +116,23 @@ __device__ __forceinline__ double plm2(double yl, double y0, double yr)
     double d1 = y0 - yl;
     double d2 = yr - y0;
     double m = __builtin_fmin(__builtin_fmin(fabs(d1), fabs(d2)) * theta2, fabs(yr - yl));
-    bool same = (__double2hiint(d1) ^ __double2hiint(d2)) >= 0;
+    int sx = __double2hiint(d1) ^ __double2hiint(d2);
+    asm("" : "+v"(sx)); // keep the sign test on the high dwords (the optimiser widens it to a 64-bit xor + compare)
+    bool same = sx >= 0;
+    return same ? copysign(m, d1) : 0.0;
+}
+
+// The same slope from the two one-sided differences d1 = y0 - yl, d2 = yr - y0 (the central difference is
+// their sum, rounded once more than yr - yl: last-place differences only).  For the y-direction, where the
+// neighbours are other lanes: d2 is the next lane's d1, one lane move instead of a move and a subtraction.
+template <int THETA10>
+__device__ __forceinline__ double plm2_diffs(double d1, double d2)
+{
+    constexpr double theta2 = 2.0 * (THETA10 / 10.0);
+    double m = __builtin_fmin(__builtin_fmin(fabs(d1), fabs(d2)) * theta2, fabs(d1 + d2));
+    int sx = __double2hiint(d1) ^ __double2hiint(d2);
+    asm("" : "+v"(sx));
+    bool same = sx >= 0;
     return same ? copysign(m, d1) : 0.0;
 }
 
@@ -130,6 +149,9 @@ __device__ __forceinline__ double plm2(double yl, double y0, double yr)
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
+#if defined(SFHIP_RSQ_RAW)
+    return r;
+#endif
     double e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-d, r, 1.0);
@@ -140,9 +162,17 @@ __device__ __forceinline__ double fast_rcp(double d)
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
+#if defined(SFHIP_RSQ_RAW) // tools/seedacc.py: accuracy of the hardware seeds themselves (2^-24.3, measured)
+    return y;
+#elif defined(SFHIP_RSQ_QUADRATIC)
+    // measured and not adopted: one Newton step leaves 2^-47.8 (18 ulp) for one instruction less, 2 % of a stage
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);
+#else
     double e = __builtin_fma(-(x * y), y, 1.0);
     double t = __builtin_fma(0.375, e, 0.5);
     return __builtin_fma(y * e, t, y);
+#endif
 }
 
 // sqrt(x) from y ~ 1/sqrt(x): s = x y corrected once with its own residual

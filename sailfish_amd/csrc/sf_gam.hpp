@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
         for (int q = 0; q < 4; ++q) { pa[q] = s0[q]; pb[q] = s1[q]; pc[q] = s2[q]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            gyb[q] = plm2<15>(from_lane_below(pb[q]), pb[q], from_lane_above(pb[q]));
-            gyc[q] = plm2<15>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]));
+            { const double d = pb[q] - from_lane_below(pb[q]); gyb[q] = plm2_diffs<15>(d, from_lane_above(d)); }
+            { const double d = pc[q] - from_lane_below(pc[q]); gyc[q] = plm2_diffs<15>(d, from_lane_above(d)); }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(pa[q]));
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 gyb[q] = gyc[q];
-                gyc[q] = plm2<15>(from_lane_below(pn[q]), pn[q], from_lane_above(pn[q]));
+                { const double d = pn[q] - from_lane_below(pn[q]); gyc[q] = plm2_diffs<15>(d, from_lane_above(d)); }
                 pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
             }
             __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         for (int q = 0; q < 3; ++q) { pa[q] = s0[q]; pb[q] = s1[q]; pc[q] = s2[q]; }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            gyb[q] = plm2<18>(from_lane_below(pb[q]), pb[q], from_lane_above(pb[q]));
-            gyc[q] = plm2<18>(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]));
+            { const double d = pb[q] - from_lane_below(pb[q]); gyb[q] = plm2_diffs<18>(d, from_lane_above(d)); }
+            { const double d = pc[q] - from_lane_below(pc[q]); gyc[q] = plm2_diffs<18>(d, from_lane_above(d)); }
         }
         // All three rows have to have arrived before the march starts: a load still pending on the loop's
         // entry edge makes the compiler wait for it inside the loop, in every iteration, behind the
@@ -471,11 +471,12 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         for (int q = 0; q < 3; ++q) pmx[q] = pb[q] + quarter * gxb[q];
         txx = pb[0] * sxx;
         txy = pb[0] * sxy;
-        // row r+1 enters the window: its y-slopes from the neighbouring lanes (2 x slope)
+        // row r+1 enters the window: its y-slopes from the neighbouring lanes (2 x slope; the upper one-sided
+        // difference is the next lane's lower one)
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             gyb[q] = gyc[q];
-            gyc[q] = plm2<18>(from_lane_below(pn[q]), pn[q], from_lane_above(pn[q]));
+            { const double d = pn[q] - from_lane_below(pn[q]); gyc[q] = plm2_diffs<18>(d, from_lane_above(d)); }
             pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
         }
         __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
