@@ -71,6 +71,26 @@ SFHIP_API int sfhip_max_nonneg(
     double *out) // :: $.numel() >= 1
 ;
 
+/* Replaces initial_condition() for the isothermal circumbinary-disk setup: the Python double
+ * loop over CircumbinaryDisk.primitive (sailfish/solvers/cbdiso_2d.py:33-46,
+ * sailfish/setups/circumbinary_disk.py:82-93) plus the host-to-device copy (cbdiso_2d.py:92-94).
+ * Fills the interior of a patch's primitive array -- zones [i0, i0 + ni) x [0, nj) of the mesh
+ * with origin (x0, y0) and spacing (dx, dy) -- in device memory; guards are left alone.
+ * softening2 = softening_length^2 as the host forms it.  Only + * / sqrt max, correctly rounded:
+ * bit-identical to the reference's loop. */
+SFHIP_API int sfhip_circumbinary_disk_primitive(
+    int ni,
+    int nj,
+    double x0,
+    double y0,
+    double dx,
+    double dy,
+    int i0, // :: $ >= 0
+    double softening2,
+    double sigma,
+    double *primitive) // :: $.shape == (ni + 4, nj + 4, 3)
+;
+
 /* ---------------------------------------------------------------- cbdiso_2d */
 
 /* Replaces cbdiso_2d_advance_rk, sailfish/solvers/cbdiso_2d.c:385-604

@@ -22,6 +22,7 @@
 #include "sf_gam.hpp"
 #include "sf_iso.hpp"
 #include "sf_reduce.hpp"
+#include "sf_setup.hpp"
 #include "sf_srhd.hpp"
 #include "sfhip.h"
 
@@ -377,6 +378,17 @@ int sfhip_max_nonneg(int n, double *x, double *out)
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(max_nonneg_kernel, dim3((unsigned)blocks), dim3(256), 0, t_stream, x, n, out);
     return check_launch("max_nonneg_kernel");
+}
+
+// Initial data of the isothermal circumbinary disk, made in place in device memory (sf_setup.hpp)
+int sfhip_circumbinary_disk_primitive(int ni, int nj, double x0, double y0, double dx, double dy, int i0,
+                                      double softening2, double sigma, double *primitive)
+{
+    if (ni < 1 || nj < 1 || i0 < 0 || !primitive) return fail(-1, "sfhip_circumbinary_disk_primitive: bad arguments");
+    dim3 block(256), grid((nj + 255) / 256, ni < 4096 ? ni : 4096);
+    hipLaunchKernelGGL(sf::disk_primitive_kernel, grid, block, 0, t_stream, ni, nj, i0, x0, y0, dx, dy, softening2,
+                       sigma, primitive);
+    return check_launch("sfhip_circumbinary_disk_primitive");
 }
 
 // ---------------------------------------------------------------------------

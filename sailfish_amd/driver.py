@@ -1,12 +1,16 @@
 """
-The part of the reference driver that is on the hot path: the fold loop with the
-CFL timestep and the Mzps metric (``sailfish/driver.py:506-517``).
+The part of the reference driver that is on the hot path -- the fold loop with the
+CFL timestep and the Mzps metric (``sailfish/driver.py:506-517``) -- and the data
+format on its far side: the checkpoint dict (``driver.py:143-189``) with restart
+from it (``driver.py:343-384, 439-449``), SURVEY.md section 8(f) rank 2.
 
-Everything else in the reference's driver (CLI, events, pickle checkpoints,
-logging, config files) is control plane and out of scope;
-the reference's own driver can drive these solvers through its solver-extension
-hook.
+Everything else in the reference's driver (CLI, events, logging, config files) is
+control plane and out of scope; the reference's own driver
+can drive these solvers through its solver-extension hook.
 """
+import os
+import pathlib
+import pickle
 from typing import NamedTuple
 
 from .kernel.system import measure_time
@@ -91,3 +95,170 @@ def run(setup_name, resolution=None, num_patches=None, mode="hip", model_paramet
         if timeseries is not None:
             timeseries.append(solver.reductions())
     return solver, reports
+
+
+# ---------------------------------------------------------------------------
+# checkpoints (reference: driver.py:143-189, 228-295, 343-384)
+# ---------------------------------------------------------------------------
+class DriverArgs(NamedTuple):
+    """The driver configuration a checkpoint carries; same fields as the reference's (driver.py:228-245)."""
+
+    setup_name: str = None
+    chkpt_file: str = None
+    model_parameters: dict = None
+    solver_options: dict = None
+    cfl_number: float = None
+    end_time: float = None
+    execution_mode: str = None
+    fold: int = None
+    resolution: int = None
+    num_patches: int = None
+    events: dict = dict()
+    new_timestep_cadence: int = None
+    verbose_output: str = ""
+
+
+class DriverState(NamedTuple):
+    """What ``write_checkpoint`` reads; same fields as the reference's (driver.py:279-295)."""
+
+    iteration: int
+    driver: DriverArgs
+    mesh: object
+    timeseries: list
+    event_states: list
+    solver: object
+    setup: object
+    cfl_number: float
+    timestep_dt: float
+
+
+CHECKPOINT_KEYS = ("iteration", "time", "timestep_dt", "cfl_number", "solution", "primitive", "timeseries", "solver",
+                   "solver_options", "event_states", "driver", "model_parameters", "setup_name", "mesh")
+
+
+def checkpoint_dict(state):
+    """
+    The dict the reference pickles (driver.py:158-174), key for key.  ``state.solver.solution`` is the
+    ``(ni, nj, NCONS)`` float64 host array without guards; in a multi-rank run gathering it is a collective
+    call, the array exists on rank 0 only and the other ranks get None back from here.
+    """
+    solution = state.solver.solution
+    primitive = state.solver.primitive
+    if solution is None:
+        return None
+    return dict(
+        iteration=state.iteration,
+        time=state.solver.time,
+        timestep_dt=state.timestep_dt,
+        cfl_number=state.cfl_number,
+        solution=solution,
+        primitive=primitive,
+        timeseries=state.timeseries,
+        solver=state.setup.solver,
+        solver_options=state.solver.options,
+        event_states=state.event_states,
+        driver=state.driver,
+        model_parameters=state.setup.model_parameter_dict(),
+        setup_name=state.setup.dash_case_class_name(),
+        mesh=state.mesh,
+        **state.setup.checkpoint_diagnostics(state.solver.time),
+    )
+
+
+def write_checkpoint(number, outdir, state):
+    """
+    Write the simulation state to ``chkpt.NNNN.pk`` / ``chkpt.<name>.pk`` under `outdir` as a pickle of
+    ``checkpoint_dict(state)`` (reference: driver.py:143-178).  Returns the file name (None on ranks > 0).
+    """
+    if type(number) is int:
+        filename = f"chkpt.{number:04d}.pk"
+    elif type(number) is str:
+        filename = f"chkpt.{number}.pk"
+    else:
+        raise ValueError("number arg must be int or str")
+    chkpt = checkpoint_dict(state)  # collective in a multi-rank run: every rank must come through here
+    if chkpt is None:
+        return None
+    if outdir is not None:
+        pathlib.Path(outdir).mkdir(parents=True, exist_ok=True)
+        filename = os.path.join(outdir, filename)
+    with open(filename, "wb") as f:
+        pickle.dump(chkpt, f)
+    return filename
+
+
+class _CheckpointUnpickler(pickle.Unpickler):
+    """
+    Checkpoints pickle application objects (mesh, driver arguments, point masses, enums).  One written by the
+    reference names them ``sailfish.<module>.<Class>``; the same classes live here under ``sailfish_amd``, with
+    the same fields, so such names are resolved to ours -- a reference checkpoint restarts here without the
+    reference installed.  (``Recurrence`` event descriptions are control plane: kept as plain tuples.)
+    """
+
+    def find_class(self, module, name):
+        if module == "sailfish" or module.startswith("sailfish."):
+            local = "sailfish_amd" + module[len("sailfish"):]
+            if name in ("Recurrence", "RecurringEvent"):
+                return _plain_record
+            if local.endswith(".driver") and name in ("DriverArgs", "DriverState"):
+                return globals()[name]
+            try:
+                return super().find_class(local, name)
+            except (ImportError, AttributeError):
+                return _plain_record
+        return super().find_class(module, name)
+
+
+def _plain_record(*args, **kwargs):
+    return dict(args=args, **kwargs)
+
+
+def load_checkpoint(chkpt_file):
+    """Load a checkpoint dict written by ``write_checkpoint`` here or by the reference (driver.py:181-189)."""
+    try:
+        with open(chkpt_file, "rb") as f:
+            return _CheckpointUnpickler(f).load()
+    except FileNotFoundError:
+        raise ValueError(f"could not open checkpoint file {chkpt_file}")
+
+
+def newest_chkpt_in_directory(directory_name):
+    """The highest-numbered ``chkpt.NNNN.pk`` in a directory that loads (reference: driver.py:192-209)."""
+    import re
+
+    expr = re.compile(r"chkpt\.([0-9]+)\.pk")
+    matches = sorted(filter(None, (expr.search(f) for f in os.listdir(directory_name))), key=lambda m: int(m.group(1)))
+    for match in reversed(matches):
+        path = os.path.join(directory_name, match.group())
+        try:
+            load_checkpoint(path)
+            return path
+        except Exception:
+            continue
+    raise ValueError("the specified directory did not have a usable checkpoint")
+
+
+def restart(chkpt, mode="hip", num_patches=None, **solver_kwargs):
+    """
+    Rebuild setup, mesh and solver from a checkpoint dict (or file name) as the reference's driver does
+    (driver.py:343-384, 439-449): model parameters and solver options from the checkpoint, the mesh from the
+    checkpointed resolution, the state through the solver's ``solution=`` argument.  Returns a ``DriverState``
+    whose iteration, cfl number and dt continue the run bit for bit.
+    """
+    if not isinstance(chkpt, dict):
+        chkpt = load_checkpoint(chkpt)
+    driver = chkpt["driver"]
+    setup = make_setup(chkpt["setup_name"], **chkpt["model_parameters"])
+    mesh = chkpt["mesh"]
+    if num_patches is None and driver is not None:
+        num_patches = getattr(driver, "num_patches", None)
+    solver = make_solver(
+        chkpt["solver"], setup.physics, dict(chkpt["solver_options"]),
+        setup=setup, mesh=mesh, time=chkpt["time"], solution=chkpt["solution"],
+        num_patches=num_patches, mode=mode, **solver_kwargs,
+    )
+    return DriverState(
+        iteration=chkpt["iteration"], driver=driver, mesh=mesh, timeseries=chkpt["timeseries"],
+        event_states=chkpt["event_states"], solver=solver, setup=setup, cfl_number=chkpt["cfl_number"],
+        timestep_dt=chkpt.get("timestep_dt"),
+    )

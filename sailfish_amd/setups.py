@@ -45,6 +45,35 @@ class Setup:
     def validate(self):
         pass
 
+    # -- what a checkpoint records about the setup (setup_base.py:221-286) ---------------------------------
+    @classmethod
+    def dash_case_class_name(cls):
+        """The name the setup is registered and checkpointed under, e.g. "circumbinary-disk"."""
+        for name, setup_class in SETUPS.items():
+            if setup_class is cls:
+                return name
+        raise SetupError(f"{cls.__name__} is not a registered setup")
+
+    def model_parameter_dict(self):
+        """Every model parameter with its current value (class-level defaults overridden by the constructor)."""
+        out = {}
+        for klass in reversed(type(self).__mro__):
+            for key, value in vars(klass).items():
+                if key.startswith("_") or callable(value) or isinstance(value, (property, classmethod, staticmethod)):
+                    continue
+                if key in ("start_time", "reference_time_scale", "default_end_time", "default_resolution",
+                           "boundary_condition"):
+                    continue
+                out[key] = getattr(self, key)
+        return out
+
+    def checkpoint_diagnostics(self, time):
+        """Post-processing data a checkpoint carries besides the state: the point masses, where the setup has
+        them (circumbinary_disk.py:214-215)."""
+        if hasattr(self, "point_masses"):
+            return dict(point_masses=self.point_masses(time))
+        return dict()
+
     def primitive_array(self, t, mesh, i0=0, i1=None, num_fields=None):
         """Fallback: the reference's per-point loop (exact by construction)."""
         i1 = mesh.ni if i1 is None else i1
@@ -143,6 +172,24 @@ class CircumbinaryDisk(Setup):
         if self.is_gamma_law and x.size <= (1 << 18):
             return Setup.primitive_points(self, t, x, y, 4)
         return self._primitive_vectorised(x, y, x.shape)
+
+    @property
+    def has_device_primitive(self):
+        """The isothermal disk's initial data can be made on the device bit for bit (only + * / sqrt max); the
+        gamma-law disk's pow/exp cannot, so that branch stays on the host."""
+        return self.is_isothermal
+
+    def device_primitive(self, lib, t, mesh, i0, i1, out):
+        """
+        Rows [i0, i1) of the initial data written straight into the interior of the device array `out`
+        ((i1 - i0 + 4, nj + 4, 3), guards untouched) by sfhip_circumbinary_disk_primitive: no host array, no
+        copy (the reference: a Python loop over every zone, cbdiso_2d.py:33-46).  Bit-identical to ``primitive``.
+        """
+        if not self.has_device_primitive:
+            raise SetupError("initial data of the gamma-law disk are made on the host")
+        lib.sfhip_circumbinary_disk_primitive[(i1 - i0, mesh.nj)](
+            mesh.x0, mesh.y0, mesh.dx, mesh.dy, i0, self.softening_length * self.softening_length,
+            float(self.initial_sigma), out)
 
     def _primitive_vectorised(self, x, y, shape):
         r2 = x * x + y * y

@@ -194,13 +194,18 @@ class PatchBase:
         self.xr, self.yr = mesh.vertex_coordinates(i1, mesh.shape[1])
         self.wavespeed_valid = False
         with self.execution_context:
-            self.primitive1 = xp.array(primitive)
-            self.primitive2 = xp.array(primitive)
-            self.primitive3 = xp.array(primitive) if (fused and rk_order == 3) else None
+            if callable(primitive):
+                # initial data made on the device: `primitive(array)` fills the interior of a zeroed array
+                self.primitive1 = xp.zeros([i1 - i0 + 2 * NG, mesh.shape[1] + 2 * NG, self.num_fields])
+                primitive(self.primitive1)
+            else:
+                self.primitive1 = xp.array(primitive)
+            self.primitive2 = self.primitive1.clone()
+            self.primitive3 = self.primitive1.clone() if (fused and rk_order == 3) else None
             self.wavespeed_max = xp.zeros(1)
             if not fused:
-                self.conserved0 = xp.zeros(primitive.shape)
-                self.wavespeeds = xp.zeros(primitive.shape[:2])
+                self.conserved0 = xp.zeros(self.primitive1.shape)
+                self.wavespeeds = xp.zeros(self.primitive1.shape[:2])
         self._coords = None
         self._reduce_workspace = None
         self.plan = None  # launch plan of the fused stage (device runs; see kernel/plan.py)
@@ -328,13 +333,22 @@ class SolverBase:
 
         self.patches = []
         rk_order = getattr(self._options, "rk_order", self.default_rk_order)
+        # initial data are made on the device where the setup can make them there bit for bit (SFHIP_HOST_IC=1:
+        # always on the host, as the reference does)
+        device_ic = (solution is None and backend.mode == "hip" and getattr(setup, "has_device_primitive", False)
+                     and hasattr(backend.lib, "sfhip_circumbinary_disk_primitive")
+                     and not os.environ.get("SFHIP_HOST_IC"))
         for n, k in enumerate(self.local_ids):
             a, b = ranges[k]
-            prim = np.zeros([b - a + 2 * NG, nj + 2 * NG, nq])
-            if solution is None:
-                prim[NG:-NG, NG:-NG] = initial_condition(setup, mesh, time, a, b)
+            if device_ic:
+                def prim(out, a=a, b=b):
+                    setup.device_primitive(backend.lib, time, mesh, a, b, out)
             else:
-                prim[NG:-NG, NG:-NG] = solution[a:b]
+                prim = np.zeros([b - a + 2 * NG, nj + 2 * NG, nq])
+                if solution is None:
+                    prim[NG:-NG, NG:-NG] = initial_condition(setup, mesh, time, a, b)
+                else:
+                    prim[NG:-NG, NG:-NG] = solution[a:b]
             device = base_device if base_device is not None else (n % max(ndev, 1))
             patch = self.patch_class(
                 time, prim, mesh, (a, b), self._physics, self._options, backend,

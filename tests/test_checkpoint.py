@@ -1,0 +1,121 @@
+"""
+The checkpoint layout (reference: sailfish/driver.py:143-189 write/load, :343-384 and
+:439-449 restart): a pickled dict whose keys, value types and array layout are the reference's, so that its
+post-processing scripts (scripts/upsample.py, to_kitp_snapshot.py, plot.py read "solution", "mesh", "driver",
+"time", "solver", "primitive", "point_masses", "model_parameters") and its restart logic find what they expect.
+A restart from the file continues the run bit for bit.
+"""
+import pickle
+
+import numpy as np
+import pytest
+
+from sailfish_amd.driver import (CHECKPOINT_KEYS, DriverArgs, DriverState, load_checkpoint, newest_chkpt_in_directory,
+                                 restart, write_checkpoint)
+from sailfish_amd.mesh import PlanarCartesian2DMesh
+from sailfish_amd.physics.circumbinary import PointMass
+from sailfish_amd.setups import make_setup
+from sailfish_amd.solvers import make_solver
+
+# the keys of the reference's state_checkpoint_dict, driver.py:158-173, in its order
+REFERENCE_KEYS = ["iteration", "time", "timestep_dt", "cfl_number", "solution", "primitive", "timeseries", "solver",
+                  "solver_options", "event_states", "driver", "model_parameters", "setup_name", "mesh"]
+
+
+def run_and_checkpoint(tmp_path, model, how, steps=3, num_patches=2, resolution=48):
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(resolution)
+    solver = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=num_patches, **how)
+    cfl = solver.recommended_cfl
+    dt = None
+    for _ in range(steps):
+        dt = solver.step(cfl)
+    driver = DriverArgs(setup_name="circumbinary-disk", model_parameters=dict(model), solver_options={}, cfl_number=cfl,
+                        execution_mode="hip", fold=10, resolution=resolution, num_patches=num_patches,
+                        new_timestep_cadence=1)
+    state = DriverState(iteration=steps, driver=driver, mesh=mesh, timeseries=[[0.0, 1.0]], event_states=[], solver=solver,
+                        setup=setup, cfl_number=cfl, timestep_dt=dt)
+    return state, write_checkpoint(steps, str(tmp_path), state)
+
+
+def check_layout_and_restart(tmp_path, model, how):
+    state, path = run_and_checkpoint(tmp_path, model, how)
+    assert path.endswith("chkpt.0003.pk") and newest_chkpt_in_directory(str(tmp_path)) == path
+    chkpt = load_checkpoint(path)
+    assert list(chkpt)[:len(REFERENCE_KEYS)] == REFERENCE_KEYS == list(CHECKPOINT_KEYS)
+    assert list(chkpt)[len(REFERENCE_KEYS):] == ["point_masses"]  # CircumbinaryDisk.checkpoint_diagnostics
+    nq = 3 if state.setup.solver == "cbdiso_2d" else 4
+    assert chkpt["solution"].shape == (48, 48, nq) and chkpt["solution"].dtype == np.float64
+    assert chkpt["primitive"] is None  # as the reference's cbd solvers: the solution array is primitive already
+    assert chkpt["solver"] == state.setup.solver and chkpt["setup_name"] == "circumbinary-disk"
+    assert chkpt["iteration"] == 3 and chkpt["time"] == state.solver.time and chkpt["timestep_dt"] == state.timestep_dt
+    assert isinstance(chkpt["mesh"], PlanarCartesian2DMesh) and chkpt["mesh"] == state.mesh
+    assert isinstance(chkpt["driver"], DriverArgs) and chkpt["driver"].resolution == 48
+    assert chkpt["driver"]._replace(resolution=96).resolution == 96          # scripts/upsample.py:13
+    assert chkpt["mesh"]._replace(ni=96, nj=96).shape == (96, 96)            # scripts/upsample.py:14
+    assert all(isinstance(m, PointMass) for m in chkpt["point_masses"]) and len(chkpt["point_masses"]) == 2
+    assert chkpt["solver_options"] == state.solver.options
+    assert chkpt["model_parameters"]["mach_number"] == 10.0 and set(model.items()) <= set(chkpt["model_parameters"].items())
+
+    # restart (driver.py:343-384, 439-449) continues bit for bit, also on a different patch count
+    expect = [state.solver.step(state.cfl_number) for _ in range(2)]  # the uninterrupted run goes on
+    final, t_final = state.solver.solution, state.solver.time
+    for num_patches in (2, 1):
+        again = restart(path, num_patches=num_patches, **how)
+        assert again.iteration == 3 and again.solver.time == chkpt["time"]
+        assert np.array_equal(again.solver.solution, chkpt["solution"])
+        dts = [again.solver.step(again.cfl_number) for _ in range(2)]
+        assert dts == expect and again.solver.time == t_final
+        assert np.array_equal(again.solver.solution, final)
+    return path
+
+
+@pytest.mark.parametrize("model", [{}, dict(eos="gamma-law")], ids=["iso", "gam"])
+def test_checkpoint_layout_and_bitwise_restart_cpu(tmp_path, model):
+    from oracle_backend import OracleBackend
+
+    check_layout_and_restart(tmp_path, model, dict(backend=OracleBackend(), distributed=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", [{}, dict(eos="gamma-law")], ids=["iso", "gam"])
+def test_checkpoint_layout_and_bitwise_restart_gpu(tmp_path, model):
+    check_layout_and_restart(tmp_path, model, dict(mode="hip"))
+
+
+def test_reference_written_checkpoint_loads_without_the_reference(tmp_path):
+    """A checkpoint written by the reference names its classes sailfish.mesh.PlanarCartesian2DMesh,
+    sailfish.driver.DriverArgs, sailfish.physics.circumbinary.PointMass / SinkModel, ...; the loader resolves
+    them to this package's classes of the same fields.  (Emulated by rewriting the class paths of a protocol-2
+    pickle, whose GLOBAL opcodes are plain text: no reference-written file exists to load, and none ships.)"""
+    from oracle_backend import OracleBackend
+
+    how = dict(backend=OracleBackend(), distributed=False)
+    state, path = run_and_checkpoint(tmp_path, {}, how)
+    ours = load_checkpoint(path)
+    blob = pickle.dumps(ours, protocol=2)
+    assert b"csailfish_amd." in blob
+    foreign = tmp_path / "chkpt.0099.pk"
+    foreign.write_bytes(blob.replace(b"csailfish_amd.", b"csailfish."))
+    with pytest.raises(ModuleNotFoundError):
+        pickle.loads(foreign.read_bytes())  # the plain unpickler would need the reference installed
+    chkpt = load_checkpoint(str(foreign))
+    assert isinstance(chkpt["mesh"], PlanarCartesian2DMesh) and isinstance(chkpt["driver"], DriverArgs)
+    assert isinstance(chkpt["point_masses"][0], PointMass) and chkpt["point_masses"] == ours["point_masses"]
+    assert np.array_equal(chkpt["solution"], ours["solution"])
+    again = restart(chkpt, **how)
+    assert again.solver.time == state.solver.time
+    assert again.solver.step(again.cfl_number) == state.solver.step(state.cfl_number)
+    assert np.array_equal(again.solver.solution, state.solver.solution)
+
+
+def test_write_checkpoint_argument_checks(tmp_path):
+    from oracle_backend import OracleBackend
+
+    state, _ = run_and_checkpoint(tmp_path, {}, dict(backend=OracleBackend(), distributed=False), steps=1,
+                                  num_patches=1, resolution=16)
+    assert write_checkpoint("final", str(tmp_path), state).endswith("chkpt.final.pk")
+    with pytest.raises(ValueError):
+        write_checkpoint(1.5, str(tmp_path), state)
+    with pytest.raises(ValueError):
+        load_checkpoint(str(tmp_path / "missing.pk"))
