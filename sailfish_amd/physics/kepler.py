@@ -21,15 +21,8 @@ class OrbitalBody(NamedTuple):
     velocity_y: float
 
 
-def solve_newton_raphson(f, g, x):
-    """Newton iteration to |f| <= 1e-15, at most 10 corrections (kepler.py:414-421)."""
-    n = 0
-    while abs(f(x)) > 1e-15:
-        x -= f(x) / g(x)
-        n += 1
-        if n > 10:
-            raise ValueError("solve_newton_rapheson: no solution")
-    return x
+KEPLER_TOLERANCE = 1e-15   # on the residual of Kepler's equation (kepler.py:416)
+KEPLER_MAX_CORRECTIONS = 11  # the reference gives up once an 11th correction has been applied (kepler.py:417-420)
 
 
 class OrbitalElements(NamedTuple):
@@ -40,6 +33,7 @@ class OrbitalElements(NamedTuple):
 
     @property
     def omega(self):
+        """Orbital angular frequency sqrt(G M / a^3), divided out one factor of a at a time as the reference does."""
         a = self.semimajor_axis
         return sqrt(NEWTON_G * self.total_mass / a / a / a)
 
@@ -48,27 +42,44 @@ class OrbitalElements(NamedTuple):
         return 2.0 * pi / self.omega
 
     def eccentric_anomaly(self, time_since_periapse):
-        p = self.period
-        t = time_since_periapse - self.period * floor(time_since_periapse / p)
+        """
+        Kepler's equation E - e sin E = M by Newton's method started from E = M (kepler.py:356-366, 414-421).
+        The time is first reduced to one orbit; the iteration stops at |residual| <= 1e-15.
+        """
+        period = self.period
+        t = time_since_periapse - self.period * floor(time_since_periapse / period)
         e = self.eccentricity
-        n = self.omega * t  # mean anomaly
-        return solve_newton_raphson(lambda k: k - e * sin(k) - n, lambda k: 1.0 - e * cos(k), n)
+        mean_anomaly = self.omega * t
+        E = mean_anomaly
+        for _ in range(KEPLER_MAX_CORRECTIONS):
+            residual = E - e * sin(E) - mean_anomaly
+            if not abs(residual) > KEPLER_TOLERANCE:
+                return E
+            E -= residual / (1.0 - e * cos(E))
+        raise ValueError("eccentric_anomaly: Newton's method did not converge")
 
     def orbital_state_from_eccentric_anomaly(self, eccentric_anomaly):
-        a, m, q, e, w = self.semimajor_axis, self.total_mass, self.mass_ratio, self.eccentricity, self.omega
-        m1 = m / (1.0 + q)
-        m2 = m - m1
-        ck = cos(eccentric_anomaly)
-        sk = sin(eccentric_anomaly)
-        x1 = -a * q / (1.0 + q) * (e - ck)
-        y1 = +a * q / (1.0 + q) * (sk) * sqrt(1.0 - e * e)
-        x2 = -x1 / q
-        y2 = -y1 / q
-        vx1 = -a * q / (1.0 + q) * w / (1.0 - e * ck) * sk
-        vy1 = +a * q / (1.0 + q) * w / (1.0 - e * ck) * ck * sqrt(1.0 - e * e)
-        vx2 = -vx1 / q
-        vy2 = -vy1 / q
-        return OrbitalBody(m1, x1, y1, vx1, vy1), OrbitalBody(m2, x2, y2, vx2, vy2)
+        """
+        Positions and velocities of the two bodies about their centre of mass (kepler.py:329-354).  Body 1 sits
+        on a lever arm a q / (1 + q), body 2 opposite at 1/q of that; every product and quotient below is taken
+        in the reference's left-to-right order (a sign flip is exact, so where the sign enters does not matter),
+        because these ten numbers become kernel arguments and must carry the reference's bits
+        (tests/golden/kepler.npz).
+        """
+        a, e, q = self.semimajor_axis, self.eccentricity, self.mass_ratio
+        mass1 = self.total_mass / (1.0 + q)
+        mass2 = self.total_mass - mass1
+        cosE, sinE = cos(eccentric_anomaly), sin(eccentric_anomaly)
+        arm = a * q / (1.0 + q)
+        axis_ratio = sqrt(1.0 - e * e)
+        rate = arm * self.omega / (1.0 - e * cosE)
+        x1 = -arm * (e - cosE)
+        y1 = arm * sinE * axis_ratio
+        vx1 = -rate * sinE
+        vy1 = rate * cosE * axis_ratio
+        body1 = OrbitalBody(mass1, x1, y1, vx1, vy1)
+        body2 = OrbitalBody(mass2, -x1 / q, -y1 / q, -vx1 / q, -vy1 / q)
+        return body1, body2
 
     def orbital_state(self, time_since_periapse):
         return self.orbital_state_from_eccentric_anomaly(self.eccentric_anomaly(time_since_periapse))
