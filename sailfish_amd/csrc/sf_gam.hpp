@@ -44,6 +44,7 @@ struct GamParams {
     // uniform values evaluated on the host so that they arrive in SGPRs (no scalar fp64 unit: formed
     // in the kernel they would sit in vector registers for the whole march)
     double half_inv_dx, half_inv_dy, one_minus_a, inv_buf_sd, sink_near2[2]; // sink_near2 = (4 r_sink)^2
+    double half_alpha;          // alpha / 2
 };
 
 // ---- exact pieces (reference-named small kernels, wavespeed/dt path) -------
@@ -200,16 +201,19 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
     {
         double am = __builtin_fmin(0.0, __builtin_fmin(vl - csL, vr - csL));
         double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csL, vr + csL));
-        double rden = fast_rcp(ap - am), apam = ap * am;
+        // (Fl ap - Fr am - dU ap am) / (ap - am) with the three weights formed once per flux
+        double rden = fast_rcp(ap - am);
+        double wl = ap * rden, wr = am * rden, wd = wl * am;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fR[q] = (fl[q] * ap - fr[q] * am - du[q] * apam) * rden;
+        for (int q = 0; q < 4; ++q) fR[q] = fl[q] * wl - fr[q] * wr - du[q] * wd;
     }
     {
         double am = __builtin_fmin(0.0, __builtin_fmin(vl - csR, vr - csR));
         double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csR, vr + csR));
-        double rden = fast_rcp(ap - am), apam = ap * am;
+        double rden = fast_rcp(ap - am);
+        double wl = ap * rden, wr = am * rden, wd = wl * am;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fL[q] = (fl[q] * ap - fr[q] * am - du[q] * apam) * rden;
+        for (int q = 0; q < 4; ++q) fL[q] = fl[q] * wl - fr[q] * wr - du[q] * wd;
     }
 }
 
@@ -443,9 +447,11 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
             const double prb = pb[3] * fast_rcp(pb[0]);
             const double qhb = sqrt_from_rsqrt(prb, fast_rsqrt(prb));
             const double csb = qhb * P.sqrt_gamma;
+            // All viscosities below are HALF the reference's nu = alpha h cs (cbdgam_2d.c:639-648): the factor 1/2
+            // of the face averages (:651-666) is folded into alpha on the host -- a power of two, the same bits.
             double nub = 0;
-            if (visc) // nu = alpha h cs at the zone centre, cbdgam_2d.c:644
-                nub = P.alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
+            if (visc) // nu / 2 at the zone centre, cbdgam_2d.c:644
+                nub = P.half_alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
 
             // Both faces are evaluated in every iteration (the first one's x-face and the last one's y-face go
             // unused), so that the fluxes are plain locals and `acc` is written unconditionally.
@@ -458,16 +464,16 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                 gam_hlle2_fast<0>(pmx, ppx, csa, csb, P.inv_gm1, FR, FL);
                 if (visc) {
                     double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, xf, oyc0, oyc1) : 1.0;
-                    double nufL = P.alpha * (hvar ? qha * iof : 1.0) * csa; // cbdgam_2d.c:639,645
-                    double nufR = P.alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:640,646
+                    double nufL = P.half_alpha * (hvar ? qha * iof : 1.0) * csa; // cbdgam_2d.c:639,645
+                    double nufR = P.half_alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:640,646
                     double txa = pa[0] * sxxa, tya = pa[0] * sxya, txb = pb[0] * sxx, tyb = pb[0] * sxy;
                     double exa = txa * pa[1] + tya * pa[2], exb = txb * pb[1] + tyb * pb[2];
-                    FR[1] -= 0.5 * (nufL * txa + nub * txb);
-                    FR[2] -= 0.5 * (nufL * tya + nub * tyb);
-                    FR[3] -= 0.5 * (nufL * exa + nub * exb);
-                    FL[1] -= 0.5 * (nua * txa + nufR * txb);
-                    FL[2] -= 0.5 * (nua * tya + nufR * tyb);
-                    FL[3] -= 0.5 * (nua * exa + nufR * exb);
+                    FR[1] -= nufL * txa + nub * txb;
+                    FR[2] -= nufL * tya + nub * tyb;
+                    FR[3] -= nufL * exa + nub * exb;
+                    FL[1] -= nua * txa + nufR * txb;
+                    FL[2] -= nua * tya + nufR * tyb;
+                    FL[3] -= nua * exa + nufR * exb;
                 }
             }
             // row r-2 is complete with its upper face (as that row sees it): -(dF/dx + dG/dy) dt
@@ -490,14 +496,14 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
                     double qhl = from_lane_below(qhb);
                     double nul = from_lane_below(nub);
                     double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, xcb, oyf0, oyf1) : 1.0;
-                    double nufL = P.alpha * (hvar ? qhl * iof : 1.0) * csl; // cbdgam_2d.c:641,647
-                    double nufR = P.alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:642,648
-                    GR[1] -= 0.5 * (nufL * txl + nub * txb);
-                    GR[2] -= 0.5 * (nufL * tyl + nub * tyb);
-                    GR[3] -= 0.5 * (nufL * exl + nub * exb);
-                    GL[1] -= 0.5 * (nul * txl + nufR * txb);
-                    GL[2] -= 0.5 * (nul * tyl + nufR * tyb);
-                    GL[3] -= 0.5 * (nul * exl + nufR * exb);
+                    double nufL = P.half_alpha * (hvar ? qhl * iof : 1.0) * csl; // cbdgam_2d.c:641,647
+                    double nufR = P.half_alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:642,648
+                    GR[1] -= nufL * txl + nub * txb;
+                    GR[2] -= nufL * tyl + nub * tyb;
+                    GR[3] -= nufL * exl + nub * exb;
+                    GL[1] -= nul * txl + nufR * txb;
+                    GL[2] -= nul * tyl + nufR * tyb;
+                    GL[3] -= nul * exl + nufR * exb;
                 }
                 // upper face of this zone is the lower face of lane j+1, seen from below
 #pragma unroll

@@ -131,11 +131,12 @@ __device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, dou
     else          { fl2 += prl; fr2 += prr; }
     double am = __builtin_fmin(0.0, __builtin_fmin(vl - cs, vr - cs));
     double ap = __builtin_fmax(0.0, __builtin_fmax(vl + cs, vr + cs));
+    // F = (Fl ap - Fr am - (Ul - Ur) ap am) / (ap - am) with the three weights formed once per face
     double rden = fast_rcp(ap - am);
-    double apam = ap * am;
-    f[0] = (fl0 * ap - fr0 * am - (pl[0] - pr[0]) * apam) * rden;
-    f[1] = (fl1 * ap - fr1 * am - (ul1 - ur1) * apam) * rden;
-    f[2] = (fl2 * ap - fr2 * am - (ul2 - ur2) * apam) * rden;
+    double wl = ap * rden, wr = am * rden, wd = wl * am;
+    f[0] = fl0 * wl - fr0 * wr - (pl[0] - pr[0]) * wd;
+    f[1] = fl1 * wl - fr1 * wr - (ul1 - ur1) * wd;
+    f[2] = fl2 * wl - fr2 * wr - (ul2 - ur2) * wd;
 }
 
 // One point mass: gravity + sink, cbdiso_2d.c:97-175.  Accumulates into dc.

@@ -258,6 +258,7 @@ void fill_gam(sf::GamParams &P, int ni, int nj, double pxl, double pxr, double p
     P.half_inv_dx = 0.5 * P.inv_dx;
     P.half_inv_dy = 0.5 * P.inv_dy;
     P.one_minus_a = 1.0 - a;
+    P.half_alpha = 0.5 * alpha;
     P.inv_buf_sd = bsd != 0.0 ? 1.0 / bsd : 0.0;
     P.sink_near2[0] = 16.0 * m1.sink_radius * m1.sink_radius;
     P.sink_near2[1] = 16.0 * m2.sink_radius * m2.sink_radius;

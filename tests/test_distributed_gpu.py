@@ -144,3 +144,48 @@ def test_two_ranks_one_gpu_dg(name):
     for rank, err, dt_err in _run_ranks(_dg_worker, lambda r: (r, world, port, name), world):
         assert err <= 1e-12, (rank, err)
         assert dt_err <= 1e-13, (rank, dt_err)
+
+
+def _nccl_single_rank_worker(port, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from sailfish_amd.physics.circumbinary import Diagnostic
+        from sailfish_amd.setups import make_setup
+        from sailfish_amd.solvers import make_solver
+
+        setup = make_setup("circumbinary-disk")
+        mesh = setup.mesh(96)
+        physics = dict(setup.physics, diagnostics=[Diagnostic("mass"), Diagnostic("mdot", accretion=True, which_mass=1)])
+        kw = dict(setup=setup, mesh=mesh, time=0.0, num_patches=2, mode="hip")
+        a = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # every collective goes through RCCL / gloo
+        b = make_solver(setup.solver, physics, {}, distributed=False, **kw)
+        assert a.comm.enabled and a.comm.size == 1 and not b.comm.enabled
+        dts_a = [a.step(0.3) for _ in range(4)]
+        dts_b = [b.step(0.3) for _ in range(4)]
+        same = dts_a == dts_b and a.maximum_wavespeed() == b.maximum_wavespeed()
+        same = same and bool(np.array_equal(a.solution, b.solution))            # gather over the gloo side group
+        same = same and a.reductions() == b.reductions()                        # per-patch sums all-gathered
+        same = same and a.comm.host_group() is not None                         # RCCL is the default group, gloo beside it
+        queue.put((0, 0.0 if same else float("inf"), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_process_group_single_rank():
+    """What can run of the RCCL path on one GPU: a one-rank `nccl` process group under the solver -- the MAX
+    all-reduce of the device-side wavespeed slot on RCCL, the gloo side group for host gathers created beside
+    it, rank-0 gather and all-gather of diagnostics -- equal to the run without torch.distributed, bit for bit.
+    (Halo slabs between ranks need two devices; their posting order is what the gloo tests cover.)"""
+    port = _free_port()
+    for rank, err, _ in _run_ranks(_nccl_single_rank_worker, lambda r: (port,), world=1):
+        assert err == 0.0
