@@ -80,6 +80,9 @@ def parse_args():
     ap.add_argument("--strong", action="store_true",
                     help="headline = the MESH held at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: measure the headline workload only")
+    ap.add_argument("--halo-transport", default=None, choices=["torch", "rccl"],
+                    help="N > 1: halo slabs and the wavespeed all-reduce through torch.distributed (default) or through "
+                         "RCCL called directly on the solver's streams (sailfish_amd/kernel/rccl.py)")
     ap.add_argument("--ramp-seconds", type=float, default=0.5,
                     help="untimed steps of the same workload run for this long BEFORE the W warmup steps, so that "
                          "the GPU's clocks have left their idle state when the (short) timed region starts; the "
@@ -387,6 +390,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
 
+    if args.halo_transport:
+        os.environ["SFHIP_HALO_TRANSPORT"] = args.halo_transport
     ranks = Ranks(args)
     world = ranks.world
     args.gpus = world
@@ -460,7 +465,9 @@ def main():
                 "zones_per_gpu": head["zones"] // world,
                 "path": "reference-order kernels" if args.unfused else "fused stage kernels",
                 "clock_ramp_steps": head["ramp_steps"],
-                "transport": None if world == 1 else ("RCCL" if args.transport == "nccl" else "gloo, all ranks on cuda:0"),
+                "transport": None if world == 1 else (
+                    ("RCCL called directly" if os.environ.get("SFHIP_HALO_TRANSPORT") == "rccl" else "RCCL through torch.distributed")
+                    if args.transport == "nccl" else "gloo, all ranks on cuda:0"),
             },
             "hbm_roofline_frac_whole_step": round(head["mzps"] * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline,

@@ -357,6 +357,12 @@ class SolverBase:
             )
             self.patches.append(patch)
         self._comm_stream = None
+        self._rccl = None
+        # "torch" (default): halo slabs and the wavespeed all-reduce through torch.distributed; "rccl": through RCCL
+        # called directly on the solver's streams (kernel/rccl.py)
+        self.halo_transport = os.environ.get("SFHIP_HALO_TRANSPORT", "torch")
+        if self.comm.enabled and backend.mode == "hip" and self.halo_transport == "rccl":
+            self._rccl = self._create_rccl()
         if backend.mode == "hip" and fused and not os.environ.get("SFHIP_NO_PLANS"):
             from ..kernel.plan import StagePlan
 
@@ -378,6 +384,25 @@ class SolverBase:
 
     def _patch_kwargs(self):
         return {}
+
+    def _create_rccl(self):
+        """Collective: every rank tries to join a direct RCCL communicator; all fall back together if any failed."""
+        from ..kernel.rccl import RcclComm
+
+        comm, error = None, None
+        try:
+            comm = RcclComm.create(self.comm.dist, self.comm.rank, self.comm.size)
+        except Exception as exc:  # a missing library, a failed bootstrap: not fatal, the default transport remains
+            error = exc
+        torch = self._torch()
+        ok = torch.tensor([0.0 if comm is None else 1.0], dtype=torch.float64, device="cuda")
+        self.comm.dist.all_reduce(ok, op=self.comm.dist.ReduceOp.MIN)
+        if float(ok.item()) != 1.0:
+            if comm is not None:
+                comm.close()
+            logger.warning(f"direct RCCL transport unavailable ({error!r}); using torch.distributed")
+            return None
+        return comm
 
     # ------------------------------------------------------------------ state
     @property
@@ -697,7 +722,11 @@ class SolverBase:
             self.advance_rk(params[stage], dt, stage, len(params), slots=(cur, nxt))
         if self.comm.enabled:
             with p0.execution_context:
-                self.comm.max_scalar(nxt)  # on the compute stream, behind the last stage; stays on the device
+                # on the compute stream, behind the last stage; the result stays on the device
+                if self._rccl is not None:
+                    self._rccl.max_scalar(nxt, self._torch().cuda.current_stream().cuda_stream)
+                else:
+                    self.comm.max_scalar(nxt)
         self._slot_cur = 1 - self._slot_cur
         self._slot_valid = True
         return dt
@@ -816,6 +845,21 @@ class SolverBase:
             return None
         dist = self.comm.dist
         torch = self._torch()
+        if self._rccl is not None:
+            # one ncclGroup of sends and receives on the comm stream: stream-ordered, nothing to wait for on the host
+            with self.patches[0].execution_context:
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream()
+                    for p in self.patches:
+                        if getattr(p, "plan", None) is not None:
+                            p.plan.set_side_stream(self._comm_stream)
+                ready = torch.cuda.Event()
+                ready.record()
+                if between is not None:
+                    between()
+                self._comm_stream.wait_event(ready)
+                self._rccl.exchange(ops, self._comm_stream.cuda_stream)
+            return "stream-ordered"
         p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops]
         if self.backend.mode == "hip":
             with self.patches[0].execution_context:
@@ -845,9 +889,10 @@ class SolverBase:
         if self.backend.mode == "hip":
             torch = self._torch()
             with self.patches[0].execution_context:
-                with torch.cuda.stream(self._comm_stream):
-                    for r in reqs:
-                        r.wait()
+                if reqs != "stream-ordered":
+                    with torch.cuda.stream(self._comm_stream):
+                        for r in reqs:
+                            r.wait()
                 if join:
                     torch.cuda.current_stream().wait_stream(self._comm_stream)
         else:

@@ -169,10 +169,25 @@ def _nccl_single_rank_worker(port, queue):
         kw = dict(setup=setup, mesh=mesh, time=0.0, num_patches=2, mode="hip")
         a = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # every collective goes through RCCL / gloo
         b = make_solver(setup.solver, physics, {}, distributed=False, **kw)
-        assert a.comm.enabled and a.comm.size == 1 and not b.comm.enabled
+        os.environ["SFHIP_HALO_TRANSPORT"] = "rccl"
+        c = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # ... through RCCL called directly
+        del os.environ["SFHIP_HALO_TRANSPORT"]
+        assert a.comm.enabled and a.comm.size == 1 and not b.comm.enabled and a._rccl is None and c._rccl is not None
         dts_a = [a.step(0.3) for _ in range(4)]
         dts_b = [b.step(0.3) for _ in range(4)]
-        same = dts_a == dts_b and a.maximum_wavespeed() == b.maximum_wavespeed()
+        dts_c = [c.step(0.3) for _ in range(4)]
+        same = dts_a == dts_b == dts_c and a.maximum_wavespeed() == b.maximum_wavespeed() == c.maximum_wavespeed()
+        same = same and bool(np.array_equal(c.solution, b.solution))
+
+        # the direct transport's grouped send / receive, to the own rank (all a one-GPU box can run)
+        x = torch.arange(1000, dtype=torch.float64, device="cuda") * 0.5
+        y = torch.zeros_like(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        c._rccl.exchange([("send", x[:600], 0), ("recv", y[:600], 0), ("send", x[600:], 0), ("recv", y[600:], 0)],
+                         side.cuda_stream)
+        side.synchronize()
+        same = same and bool(torch.equal(x, y))
         same = same and bool(np.array_equal(a.solution, b.solution))            # gather over the gloo side group
         same = same and a.reductions() == b.reductions()                        # per-patch sums all-gathered
         same = same and a.comm.host_group() is not None                         # RCCL is the default group, gloo beside it

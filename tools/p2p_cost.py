@@ -64,7 +64,25 @@ def main():
             done.record()
         torch.cuda.current_stream().wait_event(done)
 
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sailfish_amd.kernel.rccl import RcclComm
+
+    direct = RcclComm.create(dist, 0, 1)
+    comm_ptr = comm.cuda_stream
+
+    def exchange_direct():  # the same exchange through RCCL called directly (kernel/rccl.py): one group, no work objects
+        ready.record()
+        comm.wait_event(ready)
+        direct.exchange([("send", a[0], 0), ("recv", a[1], 0), ("send", a[2], 0), ("recv", a[3], 0)], comm_ptr)
+        done.record(comm)
+        torch.cuda.current_stream().wait_event(done)
+
+    cur_ptr = torch.cuda.current_stream().cuda_stream
     for name, fn in (("halo exchange (2 send + 2 recv)", exchange),
+                     ("same, RCCL called directly", exchange_direct),
+                     ("all_reduce MAX of one double, RCCL called directly", lambda: direct.max_scalar(amax, cur_ptr)),
                      ("same, events created once", exchange_cached_events),
                      ("all_gather_into_tensor of 2 slabs", gather),
                      ("all_reduce MAX of one double", lambda: dist.all_reduce(amax, op=dist.ReduceOp.MAX))):
