@@ -665,6 +665,22 @@ int sfhip_plan_fetch_wait(int plan, double *host_value);
  * *amax_device and then host_seq to the plan's pinned memory, and sfhip_plan_host_wait(plan, host_seq, &v)
  * returns that value: the host learns the reduced wavespeed without a copy or an event in the stream. */
 int sfhip_plan_host_wait(int plan, double host_seq, double *host_value);
+/* A whole RK2 step of a one-patch solver from one call, for point masses on a Kepler orbit (the
+ * circumbinary setups): stage 0 with dt formed in the kernel from *slot_current (and *slot_next zeroed, the
+ * reduced wavespeed handed to the host through the plan's pinned memory), `dt = dx / amax * cfl`
+ * (driver.py:509-510), the stage times of Patch.advance_rk (cbdiso_2d.py:239), the orbit at those times --
+ * OrbitalElements.orbital_state (physics/kepler.py:329-373, 414-421) restated on the host in C with the same
+ * libm, bit-identical -- and stage 1 folding the new wavespeed into *slot_next.  `state` holds p^n and
+ * receives the new state, `other` is the second buffer (device); elements4 = semimajor axis, total mass,
+ * mass ratio, eccentricity and shared4 = softening length, sink rate, sink radius, sink model (host);
+ * result3 (host) receives amax, dt and the time after the step.  Returns 1 when amax is below
+ * wavespeed_floor (only stage 0 was launched; the caller recomputes the wavespeed exactly and repeats). */
+int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,
+                        double dx, double cfl, double time, const double *elements4, const double *shared4,
+                        double wavespeed_floor, double host_seq, double *result3);
+/* Host only, no GPU involved: the orbital state (mass, x, y, vx, vy of body 1, then body 2) into 10 host doubles. */
+int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double mass_ratio, double eccentricity,
+                               double time_since_periapse, double *out10_host);
 
 /* ---------------------------------------------------------------------------
  * srhd_2d -- 2-D special-relativistic hydrodynamics on a log-spherical, homologously

@@ -293,6 +293,8 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
 // pattern ranks above every finite value and infinity, so it survives too.
 __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
 {
+    // (A plain load first, to skip the atomic when the value cannot raise the maximum, was measured: no
+    // difference at 512^2 or 4096^2 -- the same-address atomics of a launch's waves are not what its tail waits for.)
     atomicMax(reinterpret_cast<unsigned long long *>(addr),
               static_cast<unsigned long long>(__double_as_longlong(v)));
 }

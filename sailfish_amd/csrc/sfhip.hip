@@ -53,23 +53,33 @@ int env_int(const char *name, int fallback)
     return s && *s ? atoi(s) : fallback;
 }
 
-// Split `nrows` rows into chunks so that the launch has several waves per SIMD on all 256 CUs
-// (1024 SIMDs), without making chunks so short that the 4-row pipeline warm-up dominates:
-// about 8192 waves (8 workgroups of 4 waves per CU) and at least 32 rows per chunk.  On the
-// device the stage time is flat (+-2 %) between 34 and 69 rows per chunk, for the 4096^2 patch
-// as for the 1448 x 11584 patch of an 8-rank run (tools/sweep_shapes.sh), and ~8 % worse at 94.
-// Small patches, which cannot reach 2 waves per SIMD with 32-row chunks, go down to 8 rows.
+// Split `nrows` rows into chunks, one wave per (chunk, strip).
+// Large patches: about 8192 waves (8 workgroups of 4 waves per CU) and at least 32 rows per chunk, so that the
+// 4-row pipeline warm-up stays small.  On the device the stage time is flat (+-2 %) between 34 and 69 rows per
+// chunk, for the 4096^2 patch as for the 1448 x 11584 patch of an 8-rank run (tools/sweep_shapes.sh).
+// Patches that cannot reach that many waves with 32-row chunks trade the per-chunk overhead (4 warm-up rows plus
+// about 8 rows' worth of wave start-up and epilogue) against the number of waves, and the best chunk length grows
+// like the square root of the work: measured optima (sustained RK2 pair, tools/kbench.py) are 5 rows at 512^2,
+// 12 at 1024^2, 12-24 at 2048^2, which rows = sqrt(nrows * nstrips / 184) reproduces.  With 8-row chunks at 512^2,
+// the earlier rule, the pair took 0.044 ms against 0.0375 ms.
 void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
 {
     int rpc = env_int("SFHIP_ROWS_PER_CHUNK", 0);
     if (rpc <= 0) {
         const int target_waves = env_int("SFHIP_TARGET_WAVES", 8192);
-        int nc = (target_waves + nstrips - 1) / nstrips;
-        int max_nc = (nrows + 31) / 32;
-        if ((long)max_nc * nstrips < 2048) max_nc = (nrows + 7) / 8;
-        if (nc > max_nc) nc = max_nc;
-        if (nc < 1) nc = 1;
-        rpc = (nrows + nc - 1) / nc;
+        const int max_nc = (nrows + 31) / 32;
+        if ((long)max_nc * nstrips >= target_waves) {
+            int nc = (target_waves + nstrips - 1) / nstrips;
+            if (nc > max_nc) nc = max_nc;
+            if (nc < 1) nc = 1;
+            rpc = (nrows + nc - 1) / nc;
+        } else {
+            rpc = (int)lrint(sqrt((double)nrows * nstrips / (double)env_int("SFHIP_CHUNK_WORK", 184)));
+            if (rpc < 4) rpc = 4;
+            if (rpc > 32) rpc = 32;
+            const int nc = (nrows + rpc - 1) / rpc;
+            rpc = (nrows + nc - 1) / nc;   // equal chunks
+        }
     }
     if (rpc < 1) rpc = 1;
     *rows_per_chunk = rpc;
@@ -881,6 +891,114 @@ int sfhip_plan_fetch_wait(int plan, double *host_value)
     hipError_t e = hipEventSynchronize(pl->done);
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     *host_value = *pl->pinned;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// A whole RK2 step from one call: the Python between the two stage launches (dt, the stage time, the Kepler solve
+// for the point masses at t + dt, argument packing) is a few tens of microseconds, which is what bounds the step
+// rate of small patches once the kernels take 20 us.  Here the orbit is solved on the host in C, with the same
+// libm the Python reference calls and the reference's operations in the reference's order (kepler.py:329-373,
+// 414-421; contraction is off for host code too), so the ten numbers are bit-identical to
+// OrbitalElements.orbital_state (tests/golden/kepler.npz through sfhip_kepler_orbital_state).
+// ---------------------------------------------------------------------------
+namespace {
+
+// out: mass, x, y, vx, vy of body 1, then of body 2.  Returns 0, or -1 when Newton's method does not converge.
+int kepler_orbital_state(double a, double m, double q, double e, double time_since_periapse, double *out)
+{
+    const double w = sqrt(1.0 * m / a / a / a);                    // omega, NEWTON_G = 1 (kepler.py:296-302)
+    const double period = 2.0 * M_PI / w;
+    const double t = time_since_periapse - period * floor(time_since_periapse / period);
+    const double n = w * t;                                        // mean anomaly
+    double k = n;                                                  // eccentric anomaly, Newton from the mean anomaly
+    int corrections = 0;
+    while (fabs(k - e * sin(k) - n) > 1e-15) {
+        k -= (k - e * sin(k) - n) / (1.0 - e * cos(k));
+        if (++corrections > 10) return -1;
+    }
+    const double m1 = m / (1.0 + q);
+    const double m2 = m - m1;
+    const double ck = cos(k), sk = sin(k);
+    const double x1 = -a * q / (1.0 + q) * (e - ck);
+    const double y1 = +a * q / (1.0 + q) * (sk) * sqrt(1.0 - e * e);
+    const double vx1 = -a * q / (1.0 + q) * w / (1.0 - e * ck) * sk;
+    const double vy1 = +a * q / (1.0 + q) * w / (1.0 - e * ck) * ck * sqrt(1.0 - e * e);
+    out[0] = m1; out[1] = x1; out[2] = y1; out[3] = vx1; out[4] = vy1;
+    out[5] = m2; out[6] = -x1 / q; out[7] = -y1 / q; out[8] = -vx1 / q; out[9] = -vy1 / q;
+    return 0;
+}
+
+// the 18 doubles sfhip_plan_stage takes, from an orbital state and the four constants every mass shares
+void pack_masses(const double *body10, const double *shared4, double *masses18)
+{
+    for (int k = 0; k < 2; ++k) {
+        const double *b = body10 + 5 * k;
+        double *m = masses18 + 9 * k;
+        m[0] = b[1]; m[1] = b[2]; m[2] = b[3]; m[3] = b[4]; m[4] = b[0];
+        m[5] = shared4[0]; m[6] = shared4[1]; m[7] = shared4[2]; m[8] = shared4[3];
+    }
+}
+
+} // namespace
+
+// Host-only: the orbital state at `time_since_periapse` into 10 HOST doubles (test hook for the C restatement).
+int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double mass_ratio, double eccentricity,
+                               double time_since_periapse, double *out10_host)
+{
+    if (!out10_host) return fail(-1, "sfhip_kepler_orbital_state: null output");
+    if (kepler_orbital_state(semimajor_axis, total_mass, mass_ratio, eccentricity, time_since_periapse, out10_host))
+        return fail(-1, "sfhip_kepler_orbital_state: Newton's method did not converge");
+    return 0;
+}
+
+// One RK2 step of a one-patch solver whose point masses are a Kepler binary: stage 0 (dt formed in the kernel from
+// *slot_current, *slot_next zeroed, reduced wavespeed handed to the host), dt = dx / amax * cfl on the host, the
+// orbit at the stage time, stage 1 with the wavespeed fold into *slot_next.  `state` holds p^n and receives the
+// new state; `other` is the second buffer.  elements4: semimajor axis, total mass, mass ratio, eccentricity;
+// shared4: softening length, sink rate, sink radius, sink model.  result3 (host): amax, dt, the time after the
+// step.  Returns 0; 1 when amax came out below wavespeed_floor (only stage 0 has been launched: the caller
+// recomputes the wavespeed exactly and redoes the step); < 0 or a HIP error code on failure.
+int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,
+                        double dx, double cfl, double time, const double *elements4, const double *shared4,
+                        double wavespeed_floor, double host_seq, double *result3)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl) return -1;
+    if (!state || !other || !slot_current || !slot_next || !elements4 || !shared4 || !result3 || host_seq == 0.0)
+        return fail(-1, "sfhip_plan_step_rk2: bad arguments");
+    double body[10], masses[18], next8[8];
+    if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], time, body))
+        return fail(-1, "sfhip_plan_step_rk2: Kepler's equation did not converge");
+    pack_masses(body, shared4, masses);
+    // stage 0 (a = 0): p^n -> other; dt from the device slot
+    int rc = sfhip_plan_stage(plan, masses, nullptr, nullptr, state, other, 0.0, NAN, 0, pl->ni, 0, 0.0, nullptr,
+                              slot_current, dx, cfl, slot_next, 0, host_seq);
+    if (rc) return rc;
+    double amax = 0.0;
+    rc = sfhip_plan_host_wait(plan, host_seq, &amax);
+    if (rc) return rc;
+    result3[0] = amax;
+    if (amax < wavespeed_floor) return 1;
+    const double dt = dx / amax * cfl;                                  // driver.py:509-510
+    const double time0 = time;
+    const double t1 = time0 * 0.0 + (time + dt) * (1.0 - 0.0);          // cbdiso_2d.py:239 after stage 0
+    const double t2 = time0 * 0.5 + (t1 + dt) * (1.0 - 0.5);            // ... after stage 1
+    if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], t1, body))
+        return fail(-1, "sfhip_plan_step_rk2: Kepler's equation did not converge");
+    pack_masses(body, shared4, masses);
+    if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], t2, body))
+        return fail(-1, "sfhip_plan_step_rk2: Kepler's equation did not converge");
+    for (int k = 0; k < 2; ++k) {
+        next8[4 * k + 0] = body[5 * k + 1]; next8[4 * k + 1] = body[5 * k + 2];
+        next8[4 * k + 2] = body[5 * k + 0]; next8[4 * k + 3] = shared4[0];
+    }
+    // stage 1 (a = 1/2): other -> state in place over p^n (u^n recomputed from it), wavespeed folded into the next slot
+    rc = sfhip_plan_stage(plan, masses, next8, state, other, state, 0.5, dt, 0, pl->ni, 1, 0.5 * amax, slot_next,
+                          nullptr, 0.0, 0.0, nullptr, 0, 0.0);
+    if (rc) return rc;
+    result3[1] = dt;
+    result3[2] = t2;
     return 0;
 }
 

@@ -264,6 +264,16 @@ class CircumbinaryDisk(Setup):
             semimajor_axis=1.0, total_mass=1.0, mass_ratio=self.mass_ratio, eccentricity=self.eccentricity
         )
 
+    def kepler_binary(self):
+        """
+        What `point_masses(time)` is made of, for callers that evaluate it without Python (sfhip_plan_step_rk2):
+        the four orbital elements and the four constants both masses share (sink model as its integer value).
+        """
+        el = self.orbital_elements
+        return ((float(el.semimajor_axis), float(el.total_mass), float(el.mass_ratio), float(el.eccentricity)),
+                (float(self.softening_length), float(self.sink_rate), float(self.sink_radius),
+                 float(SinkModel[self.sink_model.upper()].value)))
+
     def point_masses(self, time):
         """circumbinary_disk.py:194-212"""
         common = dict(

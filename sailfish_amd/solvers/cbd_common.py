@@ -284,6 +284,7 @@ class SolverBase:
     num_cons = None
     patch_class = None
     default_rk_order = 2
+    _rccl = None      # direct RCCL transport (kernel/rccl.py): only solvers set up by _setup_patches may opt in
 
     def _setup_patches(self, setup, mesh, time, solution, num_patches, mode, backend, fused, distributed,
                        initial_condition):
@@ -369,6 +370,16 @@ class SolverBase:
             for p in self.patches:
                 with p.execution_context:
                     p.plan = StagePlan(p.lib, p, type(self).__module__.rsplit(".", 1)[-1])
+        # A whole RK2 step from one C call (sfhip_plan_step_rk2) where nothing needs Python between the stages:
+        # one patch, no other ranks, and point masses that are the setup's own Kepler binary.
+        self._c_step = False
+        fn = getattr(self._physics, "point_mass_function", None)
+        if (len(self.patches) == 1 and not self.comm.enabled and self.patches[0].plan is not None
+                and hasattr(setup, "kepler_binary") and getattr(fn, "__self__", None) is setup
+                and getattr(fn, "__func__", None) is getattr(type(setup), "point_masses", None)
+                and not os.environ.get("SFHIP_NO_C_STEP")):
+            self.patches[0].plan.set_kepler_binary(*setup.kepler_binary())
+            self._c_step = True
         self._mass_cache = (None, None)
         self._wavespeed_floor = 0.0
         self._dt_dev = None
@@ -695,6 +706,26 @@ class SolverBase:
                 with p0.execution_context:
                     cur.copy_(amax_dev)
             plan = getattr(p0, "plan", None)
+            if self._c_step and self.event_log is None and params == [0.0, 0.5]:
+                # everything between here and the end of the step in one C call (include/sfhip.h)
+                self._host_seq += 1.0
+                redo, amax, dt, t_after = plan.step_rk2(
+                    p0.primitive1, p0.primitive2, cur, nxt, float(dx), float(cfl_number), p0.time,
+                    floor if filtered else 0.0, self._host_seq)
+                if redo:
+                    filtered = False
+                    self._slot_valid = False
+                    continue
+                self._wavespeed_floor = 0.5 * amax
+                p0.time0 = p0.time
+                p0.time = p0.stage_time(0.0, dt)
+                p0.time = p0.stage_time(0.5, dt)  # (the buffers swap twice: the state is where it was)
+                if p0.time != t_after:
+                    raise RuntimeError(f"sfhip_plan_step_rk2 and Patch.stage_time disagree: {t_after!r} != {p0.time!r}")
+                p0.wavespeed_valid = False
+                self._slot_cur = 1 - self._slot_cur
+                self._slot_valid = True
+                return dt
             if plan is not None:
                 # stage 0 itself hands the value over through pinned memory as soon as it starts (no copy, no event)
                 self._host_seq += 1.0

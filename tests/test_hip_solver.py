@@ -238,3 +238,27 @@ def test_launch_plans_equal_library_calls(model, num_patches, rk_order, monkeypa
         runs.append((dts, s.time, s.solution))
     assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
     assert np.array_equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.parametrize("model", [{}, dict(eos="gamma-law"), dict(eccentricity=0.4, mass_ratio=0.3)],
+                         ids=["iso", "gam", "eccentric"])
+def test_one_call_step_equals_the_python_step(model, monkeypatch):
+    """sfhip_plan_step_rk2 (both stages, dt, stage times and the Kepler orbit from one C call) against the same
+    step driven from Python (SFHIP_NO_C_STEP=1): dt sequence, times and state bit for bit -- also across the
+    redo that a too-small filtered wavespeed forces, and when the two kinds of step alternate."""
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(96)
+    runs = []
+    for no_c_step in ("", "1"):
+        monkeypatch.setenv("SFHIP_NO_C_STEP", no_c_step)
+        s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, mode="hip")
+        assert s._c_step == (not no_c_step)
+        dts = [s.step(s.recommended_cfl) for _ in range(5)]
+        s._wavespeed_floor = 1e6               # the next step's wavespeed looks filtered away: exact recompute + redo
+        dts += [s.step(s.recommended_cfl) for _ in range(2)]
+        dts.append(timestep(mesh, s, s.recommended_cfl))  # the blocking API in between
+        s.advance(dts[-1])
+        dts += [s.step(s.recommended_cfl) for _ in range(2)]
+        runs.append((dts, s.time, s.solution))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert np.array_equal(runs[0][2], runs[1][2])
