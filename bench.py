@@ -281,12 +281,16 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
         torch.cuda.synchronize()
         per_step = max((time.perf_counter() - t0) / 5, 1e-5)
         ramp_steps = int(ranks.max_over_ranks(float(min(5000, int(args.ramp_seconds / per_step)))))
+        if ranks.rank == 0 and os.environ.get("SFHIP_BENCH_VERBOSE"):
+            print(f"[bench] clock ramp: {ramp_steps} steps after 5 steps at {per_step * 1e3:.3f} ms", file=sys.stderr, flush=True)
         for _ in range(ramp_steps):
             step()
         torch.cuda.synchronize()
         ramp_steps += 5
     for _ in range(warmup):
         step()
+    if ranks.rank == 0 and os.environ.get("SFHIP_BENCH_VERBOSE"):
+        print(f"[bench] ramp and warmup done at {resolution}", file=sys.stderr, flush=True)
     event_log = [] if use_events else None
     stride = max(1, args.event_stride)
     ranks.fence()
@@ -390,6 +394,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
 
+    if os.environ.get("SFHIP_BENCH_WATCHDOG"):
+        # a stuck run says where: every thread's Python stack to stderr after this many seconds, then exit
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["SFHIP_BENCH_WATCHDOG"]), exit=True)
     if args.halo_transport:
         os.environ["SFHIP_HALO_TRANSPORT"] = args.halo_transport
     ranks = Ranks(args)

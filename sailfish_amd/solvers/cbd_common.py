@@ -79,6 +79,7 @@ class Comm:
     def __init__(self, enabled):
         self.enabled = enabled
         self._host_group = _UNSET
+        self._staged = None
         if enabled:
             import torch.distributed as dist
 
@@ -101,10 +102,28 @@ class Comm:
                 distributed = False
         return cls(bool(distributed))
 
+    @property
+    def host_staged(self):
+        """
+        True when the default group is gloo.  Its point-to-point calls take a tensor's data pointer as host memory
+        and know nothing of streams: a device array handed to them is read or written by the host, through the
+        BAR, whenever the transport thread gets to it -- not ordered with the kernels that produce or consume it.
+        Device data therefore crosses a gloo group through host buffers, with the stream ordering made explicit
+        (max_scalar here, SolverBase.start_halo_exchange).  RCCL groups are stream-ordered by themselves.
+        """
+        if self._staged is None:
+            self._staged = bool(self.enabled and self.dist.get_backend() == "gloo")
+        return self._staged
+
     def max_scalar(self, tensor):
         """In-place MAX all-reduce of a one-element tensor (order independent: bit-exact)."""
         if self.enabled:
-            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.MAX)
+            if self.host_staged and getattr(tensor, "is_cuda", False):
+                host = tensor.cpu()  # waits for the current stream: the value is final
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX)
+                tensor.copy_(host)
+            else:
+                self.dist.all_reduce(tensor, op=self.dist.ReduceOp.MAX)
         return tensor
 
     def host_group(self):
@@ -284,6 +303,7 @@ class SolverBase:
     num_cons = None
     patch_class = None
     default_rk_order = 2
+    _staging = None   # pinned host buffers of the exchange over a gloo group (_start_host_staged_exchange)
     _rccl = None      # direct RCCL transport (kernel/rccl.py): only solvers set up by _setup_patches may opt in
 
     def _setup_patches(self, setup, mesh, time, solution, num_patches, mode, backend, fused, distributed,
@@ -891,6 +911,8 @@ class SolverBase:
                 self._comm_stream.wait_event(ready)
                 self._rccl.exchange(ops, self._comm_stream.cuda_stream)
             return "stream-ordered"
+        if self.backend.mode == "hip" and self.comm.host_staged:
+            return self._start_host_staged_exchange(ops, between)
         p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops]
         if self.backend.mode == "hip":
             with self.patches[0].execution_context:
@@ -913,9 +935,61 @@ class SolverBase:
             between()
         return dist.batch_isend_irecv(p2p)
 
+    def _start_host_staged_exchange(self, ops, between):
+        """
+        The exchange over a gloo group (Comm.host_staged): outgoing slabs are copied to pinned host buffers on
+        the comm stream, behind the event that marks their producer; the host waits for those copies, then posts
+        the sends and receives on host memory.  finish_halo_exchange copies what arrived into the guard slabs on
+        the comm stream.  The host blocks here, which a rehearsal of the N > 1 flow on one GPU can afford; runs
+        on several GPUs use RCCL.
+        """
+        torch = self._torch()
+        dist = self.comm.dist
+        if self._staging is None:
+            self._staging = {}
+        with self.patches[0].execution_context:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+                for p in self.patches:
+                    if getattr(p, "plan", None) is not None:
+                        p.plan.set_side_stream(self._comm_stream)
+            ready = torch.cuda.Event()
+            ready.record()
+            if between is not None:
+                between()
+            self._comm_stream.wait_event(ready)
+            staged = []
+            with torch.cuda.stream(self._comm_stream):
+                for n, (kind, t, peer) in enumerate(ops):
+                    key = (n, kind, tuple(t.shape))
+                    host = self._staging.get(key)
+                    if host is None:
+                        host = self._staging[key] = torch.empty(tuple(t.shape), dtype=t.dtype).pin_memory()
+                    if kind == "send":
+                        host.copy_(t, non_blocking=True)
+                    staged.append((kind, host, t, peer))
+                copied = torch.cuda.Event()
+                copied.record()
+            # (the comm stream is in order: the previous exchange's copies out of these buffers are complete too)
+            copied.synchronize()
+            reqs = [dist.isend(host, peer) if kind == "send" else dist.irecv(host, peer) for kind, host, _, peer in staged]
+        return ("host-staged", reqs, staged)
+
     def finish_halo_exchange(self, reqs, join=True):
         """Wait for the halos on the comm stream; with `join` the compute stream then waits for it too."""
         if not reqs:
+            return
+        if isinstance(reqs, tuple) and reqs[0] == "host-staged":
+            torch = self._torch()
+            for r in reqs[1]:
+                r.wait()
+            with self.patches[0].execution_context:
+                with torch.cuda.stream(self._comm_stream):
+                    for kind, host, t, _ in reqs[2]:
+                        if kind == "recv":
+                            t.copy_(host, non_blocking=True)
+                if join:
+                    torch.cuda.current_stream().wait_stream(self._comm_stream)
             return
         if self.backend.mode == "hip":
             torch = self._torch()
