@@ -37,6 +37,7 @@ SOLVERS = ("cbdiso_2d", "cbdgam_2d", "srhd_2d", "cbdisodg_2d")
 FLAVOURS = {"cpu": ["-DEXEC_MODE=0"], "omp": ["-DEXEC_MODE=1", "-fopenmp"]}
 # srhd_2d takes PLM_THETA / MACH_CEILING as define_macros from its Solver (srhd_2d.py:225-233; defaults
 # srhd_2d.py:66-67).  Extra builds with other values pin the oracle's run-time settings.
+PROBED = ("cbdiso_2d", "cbdgam_2d")  # extra builds <solver>_probes.so: see ref_probes.c
 MACRO_VARIANTS = {"srhd_2d": {"": [], "_theta2": ["-DPLM_THETA=2.0", "-DMACH_CEILING=100.0"]}}
 
 
@@ -78,6 +79,21 @@ def build(verbose=True):
                 if verbose:
                     print("[build_ref]", " ".join(cmd), "<", src_path)
                 subprocess.run(cmd, input=code.encode(), check=True)
+        if solver in PROBED:
+            # the same translation unit with oracle/ref_probes.c behind it: exported loops over the file-local
+            # helpers (slope, HLLE, primitive recovery) for tests/test_function_probes.py
+            probes_path = os.path.join(HERE, "ref_probes.c")
+            target = os.path.join(OUT, f"{solver}_probes.so")
+            if not os.path.exists(target) or os.path.getmtime(target) <= max(
+                os.path.getmtime(src_path), os.path.getmtime(probes_path), os.path.getmtime(__file__)
+            ):
+                with open(probes_path) as f:
+                    probes = f.read()
+                cmd = ["gcc", "-std=c99", "-O3", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-DEXEC_MODE=0",
+                       "-x", "c", "-", "-o", target, "-lm"]
+                if verbose:
+                    print("[build_ref]", " ".join(cmd), "<", src_path, "+", probes_path)
+                subprocess.run(cmd, input=f"{code}\n{probes}".encode(), check=True)
     return True
 
 

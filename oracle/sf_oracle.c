@@ -704,3 +704,35 @@ void sfo_cbdgam_2d_point_mass_source_term(
                             constant_softening, gamma_law_index);
         }
 }
+
+/*
+ * Per-function probes (tests/test_function_probes.py): the static helpers above, one call per array element, so
+ * that slope, HLLE flux and primitive recovery can be held against the reference's own helpers (oracle/_ref,
+ * through oracle/ref_probes.c) and against the device functions (tests/probes/) in isolation.
+ */
+void sfo_probe_slope(int n, double theta, const double *yl, const double *y0, const double *yr, double *g)
+{
+    for (int i = 0; i < n; ++i) g[i] = slope(yl[i], y0[i], yr[i], theta);
+}
+
+void sfo_probe_iso_hlle(int n, int dir, const double *pl, const double *pr, const double *cs2, double *flux)
+{
+    for (int i = 0; i < n; ++i) iso_hlle(pl + 3 * i, pr + 3 * i, cs2[i], dir, flux + 3 * i);
+}
+
+void sfo_probe_gam_hlle2(int n, int dir, const double *pm, const double *pp, const double *cs2_below, const double *cs2_above,
+                         double gamma, double *flux_for_above, double *flux_for_below)
+{
+    for (int i = 0; i < n; ++i)
+        gam_hlle2(pm + 4 * i, pp + 4 * i, cs2_below[i], cs2_above[i], dir, gamma, flux_for_above + 4 * i, flux_for_below + 4 * i);
+}
+
+void sfo_probe_iso_c2p(int n, const double *cons, double vmax, double dfloor, double *prim)
+{
+    for (int i = 0; i < n; ++i) iso_c2p(cons + 3 * i, prim + 3 * i, vmax, dfloor);
+}
+
+void sfo_probe_gam_c2p(int n, const double *cons, double vmax, double dfloor, double pfloor, double gamma, double *prim)
+{
+    for (int i = 0; i < n; ++i) gam_c2p(cons + 4 * i, prim + 4 * i, vmax, dfloor, pfloor, gamma);
+}

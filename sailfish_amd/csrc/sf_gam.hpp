@@ -179,6 +179,21 @@ __device__ __forceinline__ double gam_inv_omega_fast(const Mass *m, double x, do
     return fast_rsqrt(om2);
 }
 
+// Primitive recovery with floors, cbdgam_2d.c:319-345 (the divisions through a ~1-ulp reciprocal: fast_rcp).
+__device__ __forceinline__ void gam_c2p(const double *u, double gm1, double vmax, double dfloor, double pfloor, double *p)
+{
+#pragma clang fp contract(fast)
+    double rinv = fast_rcp(u[0]);
+    // max2(pressure_floor, .) of the reference: a NaN energy stays a NaN pressure (fmax would floor it)
+    double pres = (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) * rinv) * gm1;
+    pres = pres < pfloor ? pfloor : pres;
+    double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), vmax), u[1]);
+    double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), vmax), u[2]);
+    double rho = u[0];
+    if (u[0] < dfloor) { rho = dfloor; vx = 0.0; vy = 0.0; pres = pfloor; }
+    p[0] = rho; p[1] = vx; p[2] = vy; p[3] = pres;
+}
+
 // Two HLLE fluxes through one face (see header comment), cbdgam_2d.c:374-434;
 // csL / csR are the sound speeds of the zones below / above the face.
 template <int DIR>
@@ -333,7 +348,10 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
 //       active sinks, buffer on: the uniform tests on those flags drop out of the march (same formulas,
 //       results equal to the generic instantiation's up to FMA contraction; see iso_stage_kernel).
 template <bool WS, bool UN, bool FULL>
-__global__ __launch_bounds__(256, 2) void gam_stage_kernel(
+#ifndef SFHIP_GAM_WAVES
+#define SFHIP_GAM_WAVES 2
+#endif
+__global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
     GamParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
@@ -537,16 +555,8 @@ __global__ __launch_bounds__(256, 2) void gam_stage_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) u[q] = b * u[q] + P.a * w[q];
                 }
-                // cbdgam_2d.c:319-345
-                double rinv = fast_rcp(u[0]);
-                // max2(pressure_floor, .) of the reference: a NaN energy stays a NaN pressure (fmax would floor it)
-                double pres = (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) * rinv) * P.gm1;
-                pres = pres < P.pfloor ? P.pfloor : pres;
-                double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
-                double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
-                double rho = u[0];
-                if (u[0] < P.dfloor) { rho = P.dfloor; vx = 0.0; vy = 0.0; pres = P.pfloor; }
-                out[0] = rho; out[1] = vx; out[2] = vy; out[3] = pres;
+                gam_c2p(u, P.gm1, P.vmax, P.dfloor, P.pfloor, out);
+                const double rho = out[0], vx = out[1], vy = out[2], pres = out[3];
                 if (store_lane) {
                     if (WS) {
                         // same filter as the isothermal kernel: a ~1-ulp estimate decides which zones

@@ -139,6 +139,17 @@ __device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, dou
     f[2] = fl2 * wl - fr2 * wr - (ul2 - ur2) * wd;
 }
 
+// Primitive recovery with floors, cbdiso_2d.c:268-283 (the division through a ~1-ulp reciprocal: fast_rcp).
+__device__ __forceinline__ void iso_c2p(const double *u, double vmax, double dfloor, double *p)
+{
+#pragma clang fp contract(fast)
+    double rho = __builtin_fmax(u[0], dfloor);
+    double rinv = fast_rcp(rho);
+    p[0] = rho;
+    p[1] = copysign(__builtin_fmin(fabs(u[1] * rinv), vmax), u[1]);
+    p[2] = copysign(__builtin_fmin(fabs(u[2] * rinv), vmax), u[2]);
+}
+
 // One point mass: gravity + sink, cbdiso_2d.c:97-175.  Accumulates into dc.
 // `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed; `sink_reach2` =
 // (4 r_sink)^2 + rs^2.  `cold` points at the same mass in memory: what only the sink branch needs
@@ -432,12 +443,8 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                 u[1] = b * u[1] + P.a * un1;
                 u[2] = b * u[2] + P.a * un2;
             }
-            // primitive recovery with floors (cbdiso_2d.c:268-283)
-            double rho = __builtin_fmax(u[0], P.dfloor);
-            double rinv = fast_rcp(rho);
-            double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), P.vmax), u[1]);
-            double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), P.vmax), u[2]);
-            out[0] = rho; out[1] = vx; out[2] = vy;
+            iso_c2p(u, P.vmax, P.dfloor, out);
+            const double rho = out[0], vx = out[1], vy = out[2];
             if (store_lane) {
                 if (WS) {
                     // max(|v-cs|,|v+cs|) == fl(|v| + cs) for cs >= 0, so the zone's speed is

@@ -57,7 +57,7 @@ class CLib:
 def build_oracle():
     """(Re)build oracle/libsf_oracle.so if missing or stale."""
     so = os.path.join(ORACLE_DIR, "libsf_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".c")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.startswith("sf_oracle") and f.endswith(".c")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src) for src in srcs):
         subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
     return so

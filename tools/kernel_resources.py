@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 Register allocation of the marching kernels as the compiler reports it (no GPU needed):
-    python tools/kernel_resources.py [pattern ...]
+    python tools/kernel_resources.py [pattern ...] [-DMACRO=value ...]
 compiles sfhip.hip for gfx950 with -Rpass-analysis=kernel-resource-usage and prints VGPRs, SGPRs, scratch
 bytes per lane and waves per SIMD of every kernel whose demangled name contains one of the patterns
 (default: the stage / march kernels).  Development tool; a kernel that starts to spill shows up here.
@@ -16,11 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    patterns = sys.argv[1:] or ["stage_kernel", "march_kernel", "dg_advance", "reduce_kernel"]
+    flags = [a for a in sys.argv[1:] if a.startswith("-")]      # extra compiler flags, e.g. -DSFHIP_GAM_WAVES=3
+    patterns = [a for a in sys.argv[1:] if not a.startswith("-")] or ["stage_kernel", "march_kernel", "dg_advance", "reduce_kernel"]
     with tempfile.TemporaryDirectory() as tmp:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
                "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "sailfish_amd", "csrc", "sfhip.hip"),
-               "-o", os.path.join(tmp, "x.o"), "-Rpass-analysis=kernel-resource-usage"]
+               "-o", os.path.join(tmp, "x.o"), "-Rpass-analysis=kernel-resource-usage", *flags]
         text = subprocess.run(cmd, capture_output=True, text=True).stderr
     for block in re.split(r"remark: [^\n]*Function Name: ", text)[1:]:
         mangled = block.split()[0]
