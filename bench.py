@@ -292,7 +292,10 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
     if ranks.rank == 0 and os.environ.get("SFHIP_BENCH_VERBOSE"):
         print(f"[bench] ramp and warmup done at {resolution}", file=sys.stderr, flush=True)
     event_log = [] if use_events else None
-    stride = max(1, args.event_stride)
+    redos_before = getattr(solver, "wavespeed_redos", 0)
+    # every 4th step by default, but no more than 8 sampled steps in all: a bracketed step goes through the
+    # Python stages instead of the one-call step, which a long run of small steps would otherwise feel
+    stride = max(1, args.event_stride, -(-steps // 8))
     ranks.fence()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -305,7 +308,7 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
     result = dict(resolution=resolution, setup=setup, setup_name=setup_name, setup_kwargs=setup_kwargs, mesh=mesh, seconds=seconds,
                   steps=steps, zones=mesh.num_total_zones, mzps=mesh.num_total_zones * steps / seconds * 1e-6,
                   ms_per_step=seconds / steps * 1e3, event_log=event_log, stride=stride, ramp_steps=ramp_steps,
-                  patch_shape=tuple(solver.patches[0].shape))
+                  patch_shape=tuple(solver.patches[0].shape), redos=getattr(solver, "wavespeed_redos", 0) - redos_before)
     if use_events and event_log:
         result["bracket_overhead_ms"] = bracket_overhead_ms(torch)
     del solver
@@ -474,6 +477,7 @@ def main():
                 "zones_per_gpu": head["zones"] // world,
                 "path": "reference-order kernels" if args.unfused else "fused stage kernels",
                 "clock_ramp_steps": head["ramp_steps"],
+                "repeated_stage0": head["redos"],  # timed steps redone because the wavespeed fell below its filter
                 "transport": None if world == 1 else (
                     ("RCCL called directly" if os.environ.get("SFHIP_HALO_TRANSPORT") == "rccl" else "RCCL through torch.distributed")
                     if args.transport == "nccl" else "gloo, all ranks on cuda:0"),

@@ -674,10 +674,15 @@ int sfhip_plan_host_wait(int plan, double host_seq, double *host_value);
  * receives the new state, `other` is the second buffer (device); elements4 = semimajor axis, total mass,
  * mass ratio, eccentricity and shared4 = softening length, sink rate, sink radius, sink model (host);
  * result3 (host) receives amax, dt and the time after the step.  Returns 1 when amax is below
- * wavespeed_floor (only stage 0 was launched; the caller recomputes the wavespeed exactly and repeats). */
+ * wavespeed_floor (only stage 0 was launched; the caller recomputes the wavespeed exactly and repeats).
+ * Stage 1's epilogue evaluates exactly the zones that reach floor_fraction * amax (the caller's next
+ * wavespeed_floor): any value in [0, 1) gives the same bits, higher is faster until steps start to repeat. */
 int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,
                         double dx, double cfl, double time, const double *elements4, const double *shared4,
-                        double wavespeed_floor, double host_seq, double *result3);
+                        double wavespeed_floor, double floor_fraction, double host_seq, double *result3);
+/* Diagnostic: mean host microseconds per sfhip_plan_step_rk2 call by phase since the last call of this function
+ * (stage-0 launch, wait for the hand-over, dt + orbit, stage-1 launch) and the number of steps; out5 on the host. */
+int sfhip_plan_step_timing(int plan, double *out5);
 /* Host only, no GPU involved: the orbital state (mass, x, y, vx, vy of body 1, then body 2) into 10 host doubles. */
 int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double mass_ratio, double eccentricity,
                                double time_since_periapse, double *out10_host);

@@ -37,9 +37,14 @@ int fail(int code, const char *what)
     return code;
 }
 
+// Launch errors surface here; a fault INSIDE a kernel is asynchronous and would show up at some later, unrelated
+// synchronisation without a name.  SFHIP_SYNC_LAUNCHES=1 (debugging) waits for the device after every launch, so
+// that such a fault is reported by the entry point that caused it, with the kernel's name.
 int check_launch(const char *what)
 {
+    static const bool sync_launches = [] { const char *s = getenv("SFHIP_SYNC_LAUNCHES"); return s && *s && *s != '0'; }();
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && sync_launches) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         snprintf(t_error, sizeof(t_error), "%s: %s", what, hipGetErrorString(e));
         return (int)e;
@@ -687,6 +692,10 @@ struct StagePlan {
     hipEvent_t ready = nullptr, done = nullptr;
     double *pinned = nullptr;     // host view: [0] fetched value; [2] value and [3] sequence number written by a stage
     double *pinned_dev = nullptr; // device view of the same memory
+    // sfhip_plan_step_rk2's host time by phase, accumulated (ns): stage-0 launch, wait for the hand-over,
+    // dt + orbit, stage-1 launch; and the number of steps (sfhip_plan_step_timing)
+    double phase_ns[4] = {0, 0, 0, 0};
+    long steps_timed = 0;
 };
 
 constexpr int MAX_PLANS = 1024;
@@ -961,12 +970,14 @@ int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double 
 // recomputes the wavespeed exactly and redoes the step); < 0 or a HIP error code on failure.
 int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,
                         double dx, double cfl, double time, const double *elements4, const double *shared4,
-                        double wavespeed_floor, double host_seq, double *result3)
+                        double wavespeed_floor, double floor_fraction, double host_seq, double *result3)
 {
     StagePlan *pl = plan_of(plan);
     if (!pl) return -1;
     if (!state || !other || !slot_current || !slot_next || !elements4 || !shared4 || !result3 || host_seq == 0.0)
         return fail(-1, "sfhip_plan_step_rk2: bad arguments");
+    using clock = std::chrono::steady_clock;
+    const auto c0 = clock::now();
     double body[10], masses[18], next8[8];
     if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], time, body))
         return fail(-1, "sfhip_plan_step_rk2: Kepler's equation did not converge");
@@ -975,9 +986,11 @@ int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_cur
     int rc = sfhip_plan_stage(plan, masses, nullptr, nullptr, state, other, 0.0, NAN, 0, pl->ni, 0, 0.0, nullptr,
                               slot_current, dx, cfl, slot_next, 0, host_seq);
     if (rc) return rc;
+    const auto c1 = clock::now();
     double amax = 0.0;
     rc = sfhip_plan_host_wait(plan, host_seq, &amax);
     if (rc) return rc;
+    const auto c2 = clock::now();
     result3[0] = amax;
     if (amax < wavespeed_floor) return 1;
     const double dt = dx / amax * cfl;                                  // driver.py:509-510
@@ -993,12 +1006,33 @@ int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_cur
         next8[4 * k + 0] = body[5 * k + 1]; next8[4 * k + 1] = body[5 * k + 2];
         next8[4 * k + 2] = body[5 * k + 0]; next8[4 * k + 3] = shared4[0];
     }
+    const auto c3 = clock::now();
     // stage 1 (a = 1/2): other -> state in place over p^n (u^n recomputed from it), wavespeed folded into the next slot
-    rc = sfhip_plan_stage(plan, masses, next8, state, other, state, 0.5, dt, 0, pl->ni, 1, 0.5 * amax, slot_next,
+    rc = sfhip_plan_stage(plan, masses, next8, state, other, state, 0.5, dt, 0, pl->ni, 1, floor_fraction * amax, slot_next,
                           nullptr, 0.0, 0.0, nullptr, 0, 0.0);
     if (rc) return rc;
+    const auto c4 = clock::now();
+    pl->phase_ns[0] += std::chrono::duration<double, std::nano>(c1 - c0).count();
+    pl->phase_ns[1] += std::chrono::duration<double, std::nano>(c2 - c1).count();
+    pl->phase_ns[2] += std::chrono::duration<double, std::nano>(c3 - c2).count();
+    pl->phase_ns[3] += std::chrono::duration<double, std::nano>(c4 - c3).count();
+    pl->steps_timed += 1;
     result3[1] = dt;
     result3[2] = t2;
+    return 0;
+}
+
+// Mean host time per sfhip_plan_step_rk2 call by phase, in microseconds, since the plan was made or this was last
+// called: out5 = stage-0 launch (with the orbit at t), wait for the hand-over, dt + orbits at the stage times,
+// stage-1 launch, number of steps.  Resets the counters.
+int sfhip_plan_step_timing(int plan, double *out5)
+{
+    StagePlan *pl = plan_of(plan);
+    if (!pl || !out5) return -1;
+    const double n = pl->steps_timed > 0 ? (double)pl->steps_timed : 1.0;
+    for (int k = 0; k < 4; ++k) { out5[k] = pl->phase_ns[k] / n * 1e-3; pl->phase_ns[k] = 0.0; }
+    out5[4] = (double)pl->steps_timed;
+    pl->steps_timed = 0;
     return 0;
 }
 

@@ -24,9 +24,11 @@ def _bind(module):
     module.sfhip_plan_destroy.argtypes = [i]
     module.sfhip_plan_stage.argtypes = [i, _c_double_p, _c_double_p, p, p, p, d, d, i, i, i, d, p, p, d, d, p, i, d]
     module.sfhip_plan_host_wait.argtypes = [i, d, _c_double_p]
-    module.sfhip_plan_step_rk2.argtypes = [i, p, p, p, p, d, d, d, _c_double_p, _c_double_p, d, d, _c_double_p]
+    module.sfhip_plan_step_rk2.argtypes = [i, p, p, p, p, d, d, d, _c_double_p, _c_double_p, d, d, d, _c_double_p]
     module.sfhip_kepler_orbital_state.argtypes = [d, d, d, d, d, _c_double_p]
     module.sfhip_plan_step_rk2.restype = i
+    module.sfhip_plan_step_timing.argtypes = [i, _c_double_p]
+    module.sfhip_plan_step_timing.restype = i
     module.sfhip_kepler_orbital_state.restype = i
     module.sfhip_plan_fetch_begin.argtypes = [i, p]
     module.sfhip_plan_fetch_wait.argtypes = [i, _c_double_p]
@@ -111,14 +113,21 @@ class StagePlan:
         self._result = (ctypes.c_double * 3)()
         self._step = self.module.sfhip_plan_step_rk2
 
-    def step_rk2(self, state, other, slot_current, slot_next, dx, cfl, time, wavespeed_floor, host_seq):
+    def step_rk2(self, state, other, slot_current, slot_next, dx, cfl, time, wavespeed_floor, floor_fraction, host_seq):
         """One whole RK2 step (sfhip_plan_step_rk2).  Returns (redo, amax, dt, time_after)."""
         status = self._step(self.id, state.data_ptr(), other.data_ptr(), slot_current.data_ptr(), slot_next.data_ptr(),
-                            dx, cfl, time, self._elements, self._shared, wavespeed_floor, host_seq, self._result)
+                            dx, cfl, time, self._elements, self._shared, wavespeed_floor, floor_fraction, host_seq, self._result)
         if status not in (0, 1):
             raise self._error(f"sfhip_plan_step_rk2 failed ({status}): {self.lib.last_error()}")
         r = self._result
         return status == 1, r[0], r[1], r[2]
+
+    def step_timing(self):
+        """Mean host microseconds per step_rk2 call by phase since the last call of this method:
+        (stage-0 launch, wait for the hand-over, dt + orbit, stage-1 launch, steps)."""
+        out = (ctypes.c_double * 5)()
+        self.module.sfhip_plan_step_timing(self.id, out)
+        return tuple(out)
 
     def host_wait(self, host_seq):
         """The reduced wavespeed handed over by the stage that was launched with this `host_seq`."""

@@ -54,6 +54,14 @@ RATE_QUANTITIES = ("mdot", "fx", "fy", "torque", "power")
 DIAGNOSTICS_PER_LAUNCH = 8
 
 
+# The fused wavespeed epilogue evaluates exactly (IEEE, bit-identical to the reference's wavespeed kernel) only
+# the zones whose estimated speed reaches this fraction of the previous step's global maximum; a step whose new
+# maximum falls below that bar is redone from an exact recomputation, so the choice affects speed only.
+# Measured (MI355X, circumbinary disk from its analytic start): 0.5 -> 0.8 takes 1 % off a 4096^2 step and 4 % off
+# a 512^2 step; at 0.9 steps already repeat during the initial transient (0.555 -> 0.606 ms per step at 4096^2).
+WAVESPEED_FLOOR_FRACTION = float(os.environ.get("SFHIP_WS_FLOOR_FRACTION", "0.75"))
+
+
 class HipBackend:
     """The product backend: libsfhip.so kernels on torch device arrays."""
 
@@ -304,6 +312,7 @@ class SolverBase:
     patch_class = None
     default_rk_order = 2
     _staging = None   # pinned host buffers of the exchange over a gloo group (_start_host_staged_exchange)
+    wavespeed_redos = 0   # steps whose stage 0 was repeated because the filtered wavespeed fell below its floor
     _rccl = None      # direct RCCL transport (kernel/rccl.py): only solvers set up by _setup_patches may opt in
 
     def _setup_patches(self, setup, mesh, time, solution, num_patches, mode, backend, fused, distributed,
@@ -550,7 +559,7 @@ class SolverBase:
         cross-rank MAX.  After a fused step the per-patch maxima are already on
         the device (epilogue of the last stage) and no kernel runs at all.
 
-        The fused epilogue only folds zones at least half as fast as the
+        The fused epilogue only folds zones at least WAVESPEED_FLOOR_FRACTION as fast as the
         previous maximum (``wavespeed_floor``); its result is exact whenever it
         is not below that floor, which is checked here on the global value.
         """
@@ -558,13 +567,13 @@ class SolverBase:
         if self._slot_valid:  # left by step(): already reduced over patches and ranks
             value = float(self._slot_views[self._slot_cur].item())
             if not value < floor:
-                self._wavespeed_floor = 0.5 * value
+                self._wavespeed_floor = WAVESPEED_FLOOR_FRACTION * value
                 return value
         have_fused = self.fused and all(p.wavespeed_valid for p in self.patches)
         value = self._reduce_wavespeed(recompute=not have_fused)
         if have_fused and value < floor:
             value = self._reduce_wavespeed(recompute=True)
-        self._wavespeed_floor = 0.5 * value
+        self._wavespeed_floor = WAVESPEED_FLOOR_FRACTION * value
         return value
 
     def _reduce_wavespeed(self, recompute):
@@ -731,12 +740,13 @@ class SolverBase:
                 self._host_seq += 1.0
                 redo, amax, dt, t_after = plan.step_rk2(
                     p0.primitive1, p0.primitive2, cur, nxt, float(dx), float(cfl_number), p0.time,
-                    floor if filtered else 0.0, self._host_seq)
+                    floor if filtered else 0.0, WAVESPEED_FLOOR_FRACTION, self._host_seq)
                 if redo:
                     filtered = False
                     self._slot_valid = False
+                    self.wavespeed_redos += 1
                     continue
-                self._wavespeed_floor = 0.5 * amax
+                self._wavespeed_floor = WAVESPEED_FLOOR_FRACTION * amax
                 p0.time0 = p0.time
                 p0.time = p0.stage_time(0.0, dt)
                 p0.time = p0.stage_time(0.5, dt)  # (the buffers swap twice: the state is where it was)
@@ -763,9 +773,10 @@ class SolverBase:
                 # the filtered maximum is only a lower bound: recompute exactly and redo stage 0
                 filtered = False
                 self._slot_valid = False
+                self.wavespeed_redos += 1
                 continue
             break
-        self._wavespeed_floor = 0.5 * amax
+        self._wavespeed_floor = WAVESPEED_FLOOR_FRACTION * amax
         dt = dx / amax * cfl_number
         for p, wr in zip(self.patches, wrote):
             p.finish_stage(params[0], dt, wr)

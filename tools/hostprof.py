@@ -32,11 +32,19 @@ def main():
     for _ in range(20):
         solver.step(cfl)
     torch.cuda.synchronize()
+    plan = getattr(solver.patches[0], "plan", None)
+    if plan is not None:
+        plan.step_timing()  # reset
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.step(cfl)
     torch.cuda.synchronize()
     print(f"{(time.perf_counter() - t0) / args.steps * 1e6:.1f} us per step (host-bound at {args.resolution}^2)")
+    if plan is not None:
+        a, b, c, d, n = plan.step_timing()
+        if n:
+            print(f"inside sfhip_plan_step_rk2 ({int(n)} calls): stage-0 launch {a:.1f} us, wait for the hand-over {b:.1f} us, "
+                  f"dt + orbit {c:.1f} us, stage-1 launch {d:.1f} us")
     prof = cProfile.Profile()
     prof.enable()
     for _ in range(args.steps):
