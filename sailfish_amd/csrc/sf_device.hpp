@@ -293,10 +293,14 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
 // pattern ranks above every finite value and infinity, so it survives too.
 __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
 {
-    // (A plain load first, to skip the atomic when the value cannot raise the maximum, was measured: no
-    // difference at 512^2 or 4096^2 -- the same-address atomics of a launch's waves are not what its tail waits for.)
-    atomicMax(reinterpret_cast<unsigned long long *>(addr),
-              static_cast<unsigned long long>(__double_as_longlong(v)));
+    // A zero cannot raise a non-negative maximum: skip it (a NaN is not skipped).  This matters for the fused
+    // epilogue of the stage kernels, whose filter leaves most waves without any zone worth an exact evaluation:
+    // the same-address atomics of a launch serialise at ~8 ns each, 8 us for the ~1000 waves of a 512^2 launch
+    // that otherwise takes 15.  (A plain load first, to skip values below the CURRENT maximum, does not help: the
+    // waves of a one-round launch all finish together and all read the initial zero.)
+    if (!(v <= 0.0))
+        atomicMax(reinterpret_cast<unsigned long long *>(addr),
+                  static_cast<unsigned long long>(__double_as_longlong(v)));
 }
 
 // primitive_max_wavespeed, cbdiso_2d.c:340-350 == cbdgam_2d.c:401-409

@@ -494,8 +494,14 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         }
     }
     if (WS) {
+#if defined(SFHIP_DIAG_NO_WS_ATOMIC)       // diagnosis builds only (tools/build_variant.sh): what the fold's pieces cost
+        if (amax < 0.0) wmax[0] = amax;
+#elif defined(SFHIP_DIAG_NO_WS_WAVEMAX)
+        if (lane == 0) atomic_max_nonneg(wmax, amax);
+#else
         amax = wave_max_nonneg(amax);
         if (lane == 0) atomic_max_nonneg(wmax, amax);
+#endif
     }
 }
 

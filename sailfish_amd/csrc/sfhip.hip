@@ -60,13 +60,15 @@ int env_int(const char *name, int fallback)
 
 // Split `nrows` rows into chunks, one wave per (chunk, strip).
 // Large patches: about 8192 waves (8 workgroups of 4 waves per CU) and at least 32 rows per chunk, so that the
-// 4-row pipeline warm-up stays small.  On the device the stage time is flat (+-2 %) between 34 and 69 rows per
-// chunk, for the 4096^2 patch as for the 1448 x 11584 patch of an 8-rank run (tools/sweep_shapes.sh).
-// Patches that cannot reach that many waves with 32-row chunks trade the per-chunk overhead (4 warm-up rows plus
-// about 8 rows' worth of wave start-up and epilogue) against the number of waves, and the best chunk length grows
-// like the square root of the work: measured optima (sustained RK2 pair, tools/kbench.py) are 5 rows at 512^2,
-// 12 at 1024^2, 12-24 at 2048^2, which rows = sqrt(nrows * nstrips / 184) reproduces.  With 8-row chunks at 512^2,
-// the earlier rule, the pair took 0.044 ms against 0.0375 ms.
+// 4-row pipeline warm-up stays small.  On the device the stage time is flat (+-2 %) between 28 and 47 rows per
+// chunk at 4096^2, as for the 1448 x 11584 patch of an 8-rank run (tools/sweep_chunks.sh).
+// Patches that cannot reach that many waves with 32-row chunks are latency-bound, and what a launch takes is
+// what its slowest SIMD takes: (rows per chunk + 2 rows' worth of start-up) x a factor for the number of waves
+// that share a SIMD -- 1, 1.28 and 1.97 for one, two and three (measured; the third adds no throughput), with
+// another such round for what does not fit three resident waves.  The chunk length is the one that minimises this estimate; it
+// reproduces the measured optima of the sustained RK2 pair (tools/kbench.py): 3 rows at 512^2 (0.024 ms against
+// 0.038 ms with round 1's 8-row minimum), 10 at 1024^2 (0.050 against 0.060), ~20 at 2048^2, and the flat 6..20
+// of the 512 x 4096 slab of an 8-rank strong-scaling run.
 void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
 {
     int rpc = env_int("SFHIP_ROWS_PER_CHUNK", 0);
@@ -79,9 +81,15 @@ void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
             if (nc < 1) nc = 1;
             rpc = (nrows + nc - 1) / nc;
         } else {
-            rpc = (int)lrint(sqrt((double)nrows * nstrips / (double)env_int("SFHIP_CHUNK_WORK", 184)));
-            if (rpc < 4) rpc = 4;
-            if (rpc > 32) rpc = 32;
+            double best = 0.0;
+            for (int r = 3; r <= 32; ++r) {
+                const double waves_per_simd = (double)((nrows + r - 1) / r) * nstrips / 1024.0;
+                const int full_rounds = (int)(waves_per_simd / 3.0);      // three waves are resident per SIMD
+                const double rest = waves_per_simd - 3.0 * full_rounds;   // what the busiest SIMD still has to run then
+                const double sharing = 1.97 * full_rounds + (rest <= 0.0 ? 0.0 : rest <= 1.0 ? 1.0 : rest <= 2.0 ? 1.28 : 1.97);
+                const double cost = sharing * (r + 2);
+                if (rpc <= 0 || cost < best) { best = cost; rpc = r; }
+            }
             const int nc = (nrows + rpc - 1) / rpc;
             rpc = (nrows + nc - 1) / nc;   // equal chunks
         }
