@@ -25,6 +25,9 @@ Initial data are the setup's analytic disk (no RNG, no files), resident in HBM b
 Output fields beyond the driver's contract
   roofline       the stage kernel's algorithmic GB/s against the HBM peak; launch durations from HIP events
                  around the launches of every 4th timed step, minus the calibrated cost of an empty bracket
+                 `traffic`: HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
+                 same workload, run by this command as child processes before it touches the GPU (N = 1; 3 steps
+                 each); the committed profiles/traffic.json when such a pass is not possible, with the reason
   roofline_valu  what actually binds: the kernel's fp64 VALU instruction stream (count per launch from the
                  committed PMC pass, profiles/valu.json) against the issue rate of 1024 SIMDs
   cpu_baseline   the reference's own C/OpenMP kernels (oracle/_ref, built from /root/reference by
@@ -32,12 +35,16 @@ Output fields beyond the driver's contract
                  reference's order on a bounded sample of the same workload (N = 1, rank 0 only).
 """
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 # the host driver of this pool only supports dmabuf IPC: RCCL between processes needs this (already exported
@@ -79,6 +86,8 @@ def parse_args():
                     help="bracket the kernel launches of every Nth timed step with HIP events")
     ap.add_argument("--strong", action="store_true",
                     help="headline = the MESH held at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: measure the headline workload only")
     ap.add_argument("--halo-transport", default=None, choices=["torch", "rccl"],
                     help="N > 1: halo slabs and the wavespeed all-reduce through torch.distributed (default) or through "
@@ -105,6 +114,56 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.run(cmd).returncode
+
+
+DOMINANT_KERNEL = {"iso": "iso_stage_kernel", "gam": "gam_stage_kernel", "srhd": "srhd_march_kernel", "dg": "dg_advance_kernel"}
+
+
+def live_traffic(args, resolution):
+    """
+    HBM bytes per launch of the dominant kernel, measured now: two child runs of this file under
+    ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE: one counter block per pass), 3 steps of the same workload
+    each, started before this process has touched the GPU.  Bytes as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes for gfx950: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the kernel's launches.
+    Returns (bytes or None, how it was obtained or why not).
+    """
+    if args.no_traffic_pass:
+        return None, "--no-traffic-pass"
+    if os.environ.get("SFHIP_BENCH_CHILD"):
+        return None, "this is a counter pass itself"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "already running under a profiler"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    pattern = DOMINANT_KERNEL[args.solver]
+    env = dict(os.environ, SFHIP_BENCH_CHILD="1", TMPDIR="/tmp")
+    mean = {}
+    tmp = tempfile.mkdtemp(prefix="sfhip_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["timeout", "-s", "KILL", "90", rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--solver", args.solver, "--resolution", str(resolution),
+                   "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline", "--no-events"]
+            done = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+            if done.returncode != 0:
+                return None, f"the {counter} pass ended with status {done.returncode}"
+            values = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if pattern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            values.append(float(row["Counter_Value"]))
+            if not values:
+                return None, f"the {counter} pass recorded no launch of {pattern}"
+            mean[counter] = sum(values) / len(values)
+            launches = len(values)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return round((2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0), (
+        f"measured by this command: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of the same workload "
+        f"(3 steps, {launches} launches each), (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch")
 
 
 def recorded(table, solver, resolution, world):
@@ -348,7 +407,12 @@ def roofline_of(args, run, world):
         alg_bytes = sum(v[2] for v in per_kernel.values())
         kernel = "sf::iso_stage_kernel" if args.solver == "iso" else "sf::gam_stage_kernel"
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    traffic = recorded("traffic", solver, resolution, world)
+    traffic, traffic_source = run.get("live_traffic", (None, None))
+    if traffic is None:
+        why = traffic_source
+        traffic = recorded("traffic", solver, resolution, world)
+        traffic_source = None if traffic is None else (
+            "profiles/traffic.json (committed PMC passes of this shape)" + (f"; no live pass: {why}" if why else ""))
     roofline = dict(
         bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
@@ -361,9 +425,8 @@ def roofline_of(args, run, world):
              "runs alone (the events keep it from overlapping its neighbours' ramp-up and drain), so the two "
              "stages' durations can add up to slightly more than ms_per_step",
     )
-    if traffic is None:
-        roofline["traffic_note"] = (f"no PMC pass was recorded for {solver} at {resolution}^2 on {world} GPU(s): "
-                                    "profiles/traffic.json holds the profiled shapes")
+    roofline["traffic_note"] = traffic_source or (f"no PMC pass was recorded for {solver} at {resolution}^2 on {world} "
+                                                  "GPU(s): profiles/traffic.json holds the profiled shapes")
     valu = None
     insts = recorded("valu", solver, resolution, world)
     if insts:
@@ -404,8 +467,7 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["SFHIP_BENCH_WATCHDOG"]), exit=True)
     if args.halo_transport:
         os.environ["SFHIP_HALO_TRANSPORT"] = args.halo_transport
-    ranks = Ranks(args)
-    world = ranks.world
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
 
     if args.solver == "srhd":
@@ -418,7 +480,11 @@ def main():
     strong = (args.strong or args.resolution is not None) and world > 1
 
     use_events = not args.no_events and not args.unfused
+    # the counter passes are child processes: they come first, while this process has not touched the GPU
+    traffic_now = live_traffic(args, resolution) if world == 1 and use_events else (None, "N > 1" if world > 1 else None)
+    ranks = Ranks(args)
     head = measure(args, ranks, args.solver, resolution, args.steps, args.warmup, use_events)
+    head["live_traffic"] = traffic_now
     bytes_per_update = 5 * 8.0 * NCONS[args.solver]
     if args.solver == "srhd":
         bytes_per_update = SRHD_BYTES_PER_ZONE_UPDATE

@@ -50,7 +50,7 @@ def test_bench_two_ranks_reports_both_scaling_series():
 
 @pytest.mark.gpu
 def test_bench_single_gpu_line_has_the_contract_fields():
-    line = run_bench("--steps", "4", "--warmup", "2", "--resolution", "512", "--cpu-seconds", "1")
+    line = run_bench("--steps", "4", "--warmup", "2", "--resolution", "512", "--cpu-seconds", "1", "--no-traffic-pass")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -60,6 +60,17 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     # kernel time sampled inside the timed region cannot exceed the step it is part of by more than sampling noise
     assert sum(line["kernel_ms"].values()) <= 1.25 * line["ms_per_step"]
     assert line["cpu_baseline"]["value"] > 0.0 and line["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.gpu
+def test_bench_measures_hbm_traffic_itself():
+    """roofline.traffic comes from two rocprofv3 --pmc child passes of the same workload (FETCH_SIZE, WRITE_SIZE),
+    run by the bench before it touches the GPU; measured bytes cannot be below the algorithmic ones and, for a
+    kernel that reads every row once per strip, stay within 1.5x of them."""
+    line = run_bench("--steps", "4", "--warmup", "2", "--resolution", "1024", "--no-cpu-baseline")
+    r = line["roofline"]
+    assert r["traffic_note"].startswith("measured by this command"), r["traffic_note"]
+    assert r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.5 * r["algorithmic_bytes_per_launch"]
 
 
 def test_bench_launcher_builds_the_torchrun_command(monkeypatch):
