@@ -41,6 +41,7 @@ import json
 import math
 import os
 import shutil
+import signal
 import socket
 import subprocess
 import sys
@@ -143,12 +144,20 @@ def live_traffic(args, resolution):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
-            cmd = ["timeout", "-s", "KILL", "90", rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--solver", args.solver, "--resolution", str(resolution),
                    "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline", "--no-events"]
-            done = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
-            if done.returncode != 0:
-                return None, f"the {counter} pass ended with status {done.returncode}"
+            # a session of its own, so that a pass that hangs can be ended together with whatever it started
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                status = proc.wait(timeout=90)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f"the {counter} pass did not finish within 90 s"
+            if status != 0:
+                return None, f"the {counter} pass ended with status {status}"
             values = []
             for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
