@@ -483,7 +483,9 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
     }
     if (P.want_ws) {
         speed = wave_max_nonneg(speed);
-        if (threadIdx.x == 0) atomic_max_nonneg(wavespeed_max, speed);
+        // 65 536 one-wave blocks at 2048^2, finishing over 2 ms: a plain load first skips the same-address atomic for
+        // every wave that cannot raise the maximum any more (1-2 % of the stage)
+        if (threadIdx.x == 0 && !(speed <= *(volatile double *)wavespeed_max)) atomic_max_nonneg(wavespeed_max, speed);
     }
 }
 
