@@ -262,3 +262,24 @@ def test_one_call_step_equals_the_python_step(model, monkeypatch):
         runs.append((dts, s.time, s.solution))
     assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
     assert np.array_equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.parametrize("model", [{}, dict(eos="gamma-law")], ids=["iso", "gam"])
+def test_wavespeed_filter_fraction_does_not_change_the_bits(model, monkeypatch):
+    """The fused epilogue evaluates exactly only the zones that reach a fraction of the previous maximum, and a step
+    whose maximum falls below that bar is repeated from an exact recomputation: whatever the fraction -- none at
+    all, the default, one so high that steps do repeat -- dt sequence and state are the same, bit for bit."""
+    from sailfish_amd.solvers import cbd_common
+
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(96)
+    runs, redos = [], []
+    for fraction in (0.0, cbd_common.WAVESPEED_FLOOR_FRACTION, 0.9999):
+        monkeypatch.setattr(cbd_common, "WAVESPEED_FLOOR_FRACTION", fraction)
+        s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, mode="hip")
+        dts = [s.step(s.recommended_cfl) for _ in range(12)]
+        runs.append((dts, s.time, s.solution))
+        redos.append(s.wavespeed_redos)
+    assert redos[0] == 0 and redos[2] > 0, redos  # the highest bar is missed whenever the maximum falls at all
+    for other in runs[1:]:
+        assert other[0] == runs[0][0] and other[1] == runs[0][1] and np.array_equal(other[2], runs[0][2])
