@@ -173,9 +173,10 @@ template <bool FULL = false>
 __device__ __forceinline__ double gam_inv_omega_fast(const Mass *m, double x, double c0, double c1)
 {
 #pragma clang fp contract(fast)
+    // (explicit operations: the bring-up before the march and the march itself evaluate this for the same zone)
     double om2 = 0.0;
-    if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; double y = fast_rsqrt(d * d + c0); om2 += m[0].mass * (y * y * y); }
-    if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; double y = fast_rsqrt(d * d + c1); om2 += m[1].mass * (y * y * y); }
+    if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; double y = fast_rsqrt(__builtin_fma(d, d, c0)); om2 = __builtin_fma(m[0].mass, y * y * y, om2); }
+    if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; double y = fast_rsqrt(__builtin_fma(d, d, c1)); om2 = __builtin_fma(m[1].mass, y * y * y, om2); }
     return fast_rsqrt(om2);
 }
 
@@ -344,6 +345,36 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
     u[3] += sigma * (ec - eps);
 }
 
+// What a row contributes to the faces around it, from the window (rows below, itself, above) and its y-slopes: twice
+// its x-slopes, its strain (cbdgam_2d.c:278-293, slopes carried doubled), sqrt(p/sigma), its sound speed
+// (cbdgam_2d.c:231-236) and HALF its viscosity nu = alpha h cs at the zone centre (cbdgam_2d.c:644; the factor 1/2
+// of the face averages, :651-666, is folded into alpha on the host -- a power of two, the same bits).  The
+// bring-up before the march and the march itself both call this for the row below a chunk's first, and a zone's
+// bits must not depend on which of the two did: explicit operations only, nothing the compiler could contract one
+// way here and another way there.
+template <bool FULL>
+__device__ __forceinline__ void gam_row_state(const GamParams &P, const double *pa, const double *pb, const double *pc,
+                                              const double *gyb, bool visc, bool hvar, double hidx, double hidy,
+                                              double xcb, double oyc0, double oyc1, double *gxb, double &sxx,
+                                              double &syy, double &sxy, double &qhb, double &csb, double &nub)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gxb[q] = plm2<15>(pa[q], pb[q], pc[q]); // 2 x slope
+    sxx = 0.0; syy = 0.0; sxy = 0.0;
+    if (visc) {
+        const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
+        const double ax = gxb[1] * hidx, by = gyb[2] * hidy;
+        sxx = __builtin_fma(c43, ax, -(c23 * by));
+        syy = __builtin_fma(c43, by, -(c23 * ax));
+        sxy = __builtin_fma(gxb[2], hidx, gyb[1] * hidy);
+    }
+    const double prb = pb[3] * fast_rcp(pb[0]);
+    qhb = sqrt_from_rsqrt(prb, fast_rsqrt(prb));
+    csb = qhb * P.sqrt_gamma;
+    nub = 0.0;
+    if (visc) nub = P.half_alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
+}
+
 // FULL: the benchmark's physics, established on the host -- alpha viscosity on, both masses positive with
 //       active sinks, buffer on: the uniform tests on those flags drop out of the march (same formulas,
 //       results equal to the generic instantiation's up to FMA contraction; see iso_stage_kernel).
@@ -398,7 +429,6 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
     const double oyc0 = dyc0 * dyc0 + 1e-12, oyc1 = dyc1 * dyc1 + 1e-12;                       // omega at centres / x-faces
     const double oyf0 = (yf - P.m[0].y) * (yf - P.m[0].y) + 1e-12, oyf1 = (yf - P.m[1].y) * (yf - P.m[1].y) + 1e-12;
     const double yc2 = yc * yc;
-    const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
     const double hidx = P.half_inv_dx, hidy = P.half_inv_dy; // slopes are carried doubled
     // 0.25 is not an inline constant on gfx9 (see sf_iso.hpp): keep it as an opaque SGPR operand
     double quarter = 0.25;
@@ -432,10 +462,31 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(pa[q]));
     }
+    auto enter = [&](const double *row_in) { // a row enters the window: its y-slopes from the neighbouring lanes (2 x slope)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            gyb[q] = gyc[q];
+            { const double d = row_in[q] - from_lane_below(row_in[q]); gyc[q] = plm2_diffs<15>(d, from_lane_above(d)); }
+            pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = row_in[q];
+        }
+    };
+    // Bring-up: all that row I0-1 has to provide is the lower side of the x-face between it and row I0 (see
+    // sf_iso.hpp: a whole iteration of the march used to be spent on it).
+    {
+        const double *src = row(I0 + 1);
+        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
+        double gx[4], sxx, syy, sxy;
+        gam_row_state<FULL>(P, pa, pb, pc, gyb, visc, hvar, hidx, hidy, P.xl + ((I0 - 1 - NG) + 0.5) * P.dx, oyc0, oyc1,
+                            gx, sxx, syy, sxy, qha, csa, nua);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pmx[q] = __builtin_fma(quarter, gx[q], pb[q]);
+        sxxa = sxx; sxya = sxy;
+        enter(pn);
+    }
 
 #pragma unroll 1
-    for (int r = I0; r <= I1 + 1; ++r) {
-        const bool upd = r - 2 >= I0; // the first two iterations only bring the pipeline up
+    for (int r = I0 + 1; r <= I1 + 1; ++r) {
+        const bool upd = r - 2 >= I0; // the first iteration only brings the pipeline up
         if (UN && upd) {
             // u^n of the row updated at the bottom of this iteration: the whole iteration covers its latency
             const double *us = unsrc + (long)(r - 2) * si + ucol;
@@ -448,28 +499,12 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
         __builtin_amdgcn_sched_barrier(0); // keep the requests first
 
         {
-            double gxb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gxb[q] = plm2<15>(pa[q], pb[q], pc[q]); // 2 x slope
-            double sxx = 0, syy = 0, sxy = 0;
-            if (visc) {
-                double ax = gxb[1] * hidx, by = gyb[2] * hidy;
-                sxx = c43 * ax - c23 * by;
-                syy = c43 * by - c23 * ax;
-                sxy = gxb[2] * hidx + gyb[1] * hidy;
-            }
-
             const double xf = P.xl + (double)(r - 1 - NG) * P.dx;
             const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;
-            // sqrt(p/sigma) and sound speed of row r-1 (cbdgam_2d.c:231-236): cs = sqrt(gamma p/sigma)
-            const double prb = pb[3] * fast_rcp(pb[0]);
-            const double qhb = sqrt_from_rsqrt(prb, fast_rsqrt(prb));
-            const double csb = qhb * P.sqrt_gamma;
-            // All viscosities below are HALF the reference's nu = alpha h cs (cbdgam_2d.c:639-648): the factor 1/2
-            // of the face averages (:651-666) is folded into alpha on the host -- a power of two, the same bits.
-            double nub = 0;
-            if (visc) // nu / 2 at the zone centre, cbdgam_2d.c:644
-                nub = P.half_alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
+            // row r-1: slopes, strain, sqrt(p/sigma), sound speed, nu / 2 at the zone centre (all viscosities below
+            // are HALF the reference's nu, cbdgam_2d.c:639-648: see gam_row_state)
+            double gxb[4], sxx, syy, sxy, qhb, csb, nub;
+            gam_row_state<FULL>(P, pa, pb, pc, gyb, visc, hvar, hidx, hidy, xcb, oyc0, oyc1, gxb, sxx, syy, sxy, qhb, csb, nub);
 
             // Both faces are evaluated in every iteration (the first one's x-face and the last one's y-face go
             // unused), so that the fluxes are plain locals and `acc` is written unconditionally.
@@ -497,7 +532,7 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
             // row r-2 is complete with its upper face (as that row sees it): -(dF/dx + dG/dy) dt
 #pragma unroll
             for (int q = 0; q < 4; ++q) tot[q] = __builtin_fma(-FL[q], kx, acc[q]);
-            {
+            if (r <= I1) { // (the row above the chunk's last one is somebody else's: its y-fluxes are not needed here)
                 // y-face between lane j-1 (L) and this lane (R), row r-1
                 double pmy[4], ppy[4], GR[4], GL[4];
 #pragma unroll
@@ -571,15 +606,9 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pmx[q] = pb[q] + quarter * gxb[q];
+            for (int q = 0; q < 4; ++q) pmx[q] = __builtin_fma(quarter, gxb[q], pb[q]);
             sxxa = sxx; sxya = sxy; csa = csb; qha = qhb; nua = nub;
-            // row r+1 enters the window: its y-slopes from the neighbouring lanes (2 x slope)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                gyb[q] = gyc[q];
-                { const double d = pn[q] - from_lane_below(pn[q]); gyc[q] = plm2_diffs<15>(d, from_lane_above(d)); }
-                pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
-            }
+            enter(pn); // row r+1 enters the window
             __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
             if (upd && store_lane) {
                 const long c = (long)(r - 2) * si + (long)J * sj;

@@ -240,6 +240,36 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
 // WS: 0 no wavespeed epilogue; 1 epilogue with its own masses P.mw (output time != stage time: RK1, RK3);
 //     2 epilogue when P.mw == P.m bit for bit (last stage of RK2): the softened distances of the
 //     source terms are reused for the sound-speed estimate.
+// What a row contributes to the faces around it, from the window (rows below, itself, above) and its y-slopes:
+// twice its x-slopes and its strain (cbdiso_2d.c:248-263, slopes carried doubled).  And what it leaves behind for
+// the x-face above it: the lower-side state of that face and its viscous stresses.  The bring-up before the march
+// and the march itself both call these, and a zone's bits must not depend on which of the two evaluated its
+// neighbour: explicit operations only, nothing the compiler could contract one way here and another way there.
+__device__ __forceinline__ void iso_row_slopes(const double *pa, const double *pb, const double *pc, const double *gyb,
+                                               bool visc, double hidx, double hidy,
+                                               double *gxb, double &sxx, double &syy, double &sxy)
+{
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gxb[q] = plm2<18>(pa[q], pb[q], pc[q]); // 2 x slope
+    sxx = 0.0; syy = 0.0; sxy = 0.0;
+    if (visc) {
+        const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
+        const double ax = gxb[1] * hidx, by = gyb[2] * hidy;
+        sxx = __builtin_fma(c43, ax, -(c23 * by));
+        syy = __builtin_fma(c43, by, -(c23 * ax));
+        sxy = __builtin_fma(gxb[2], hidx, gyb[1] * hidy);
+    }
+}
+
+__device__ __forceinline__ void iso_row_leaves(const double *pb, const double *gxb, double sxx, double sxy, double quarter,
+                                               double *pmx, double &txx, double &txy)
+{
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pmx[q] = __builtin_fma(quarter, gxb[q], pb[q]);
+    txx = pb[0] * sxx;
+    txy = pb[0] * sxy;
+}
+
 // FULL: the benchmark's physics, established on the host -- viscosity on, locally isothermal EOS with both
 //       masses positive, buffer on.  The uniform tests on those flags (and the selects and zero defaults the
 //       untaken sides need) drop out of the march.  The formulas are unchanged; the compiler contracts a few
@@ -302,7 +332,6 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         cyw0 = (yc - P.mw[0].y) * (yc - P.mw[0].y) + P.mw[0].rsoft * P.mw[0].rsoft;
         cyw1 = (yc - P.mw[1].y) * (yc - P.mw[1].y) + P.mw[1].rsoft * P.mw[1].rsoft;
     }
-    const double c43 = 4.0 / 3.0, c23 = 2.0 / 3.0;
     const double hidx = P.half_inv_dx, hidy = P.half_inv_dy; // slopes are carried doubled
     // 0.25 is not an inline constant on gfx9: as a literal it forces v_mov + v_fmac (VOP2) for every
     // p +- 0.25 g.  Held opaquely in an SGPR pair it is a plain operand of a 3-address v_fma_f64.
@@ -344,6 +373,26 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     }
     constexpr bool want_un = UN;
     const long ucol = (long)(J < nj + 2 * NG ? J : nj + 2 * NG - 1) * sj;
+    auto enter = [&](const double *row_in) { // a row enters the window: its y-slopes from the neighbouring lanes
+        // (2 x slope; the upper one-sided difference is the next lane's lower one), then the window slides
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gyb[q] = gyc[q];
+            { const double d = row_in[q] - from_lane_below(row_in[q]); gyc[q] = plm2_diffs<18>(d, from_lane_above(d)); }
+            pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = row_in[q];
+        }
+    };
+    // Bring-up: all that the faces of row I0-1 have to provide is the lower side of the x-face between rows I0-1
+    // and I0.  (Round 1 ran a whole iteration of the march for it, both fluxes included: one wasted iteration per
+    // chunk, which is a fifth of the work of the 3-row chunks of a small patch.)
+    {
+        const double *src = row(I0 + 1);
+        pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
+        double gx[3], sxx, syy, sxy;
+        iso_row_slopes(pa, pb, pc, gyb, visc, hidx, hidy, gx, sxx, syy, sxy);
+        iso_row_leaves(pb, gx, sxx, sxy, quarter, pmx, txx, txy);
+        enter(pn);
+    }
 
     // One iteration of the march; on entry `pc` holds row r.  The first two iterations only bring the
     // pipeline up (faces of rows I0-1 and I0; nothing to update yet: `upd` false).  There is ONE instance of
@@ -359,7 +408,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     // wait for it there), and the next requests follow as the first thing of the next iteration: whatever a
     // wait drains is then most of an iteration old.
 #pragma unroll 1
-    for (int r = I0; r <= I1 + 1; ++r) {
+    for (int r = I0 + 1; r <= I1 + 1; ++r) {
         const bool upd = r - 2 >= I0;
         if (upd && want_un) {
             // u^n of the row updated in this iteration: in flight during both face blocks
@@ -367,21 +416,17 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
             un[0] = us[0]; un[1] = us[1]; un[2] = us[2];
         }
         { // (the last iteration's request is never consumed: a clamped, valid row; saves a branch)
+#if defined(SFHIP_DIAG_SAME_ROW)  // diagnosis builds only: every request hits the cache (what the loads' latency costs)
+            const double *src = row(I0 + (r & 1));
+#else
             const double *src = row(r + 1);
+#endif
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
         }
         __builtin_amdgcn_sched_barrier(0); // keep the requests first (the scheduler would sink them by ~150 instructions)
         // row r-1 now has both neighbours: x-slopes and strain (cbdiso_2d.c:248-263)
-        double gxb[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) gxb[q] = plm2<18>(pa[q], pb[q], pc[q]); // 2 x slope
-        double sxx = 0, syy = 0, sxy = 0;
-        if (visc) {
-            double ax = gxb[1] * hidx, by = gyb[2] * hidy;
-            sxx = c43 * ax - c23 * by;
-            syy = c43 * by - c23 * ax;
-            sxy = gxb[2] * hidx + gyb[1] * hidy;
-        }
+        double gxb[3], sxx, syy, sxy;
+        iso_row_slopes(pa, pb, pc, gyb, visc, hidx, hidy, gxb, sxx, syy, sxy);
 
         const double xf = P.xl + (double)(r - 1 - NG) * P.dx;       // lower x-face of row r-1
         const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;      // centre of row r-1
@@ -406,7 +451,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         // row r-2 is complete with its upper face: -(dF/dx + dG/dy) dt (cbdiso_2d.c:593-596)
 #pragma unroll
         for (int q = 0; q < 3; ++q) tot[q] = __builtin_fma(-F[q], kx, acc[q]);
-        {
+        if (r <= I1) { // (the row above the chunk's last one is somebody else's: its y-fluxes are not needed here)
             // y-face below this lane's zone in row r-1 (cbdiso_2d.c:543-546, 562-563, 583-586)
             double pmy[3], ppy[3], G[3], c2, cs;
 #pragma unroll
@@ -474,19 +519,9 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                 }
             }
         }
-        // slide the window: row r-1 becomes the lower side of the next x-face
-#pragma unroll
-        for (int q = 0; q < 3; ++q) pmx[q] = pb[q] + quarter * gxb[q];
-        txx = pb[0] * sxx;
-        txy = pb[0] * sxy;
-        // row r+1 enters the window: its y-slopes from the neighbouring lanes (2 x slope; the upper one-sided
-        // difference is the next lane's lower one)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            gyb[q] = gyc[q];
-            { const double d = pn[q] - from_lane_below(pn[q]); gyc[q] = plm2_diffs<18>(d, from_lane_above(d)); }
-            pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
-        }
+        // slide the window: row r-1 becomes the lower side of the next x-face, row r+1 enters
+        iso_row_leaves(pb, gxb, sxx, sxy, quarter, pmx, txx, txy);
+        enter(pn);
         __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
         if (upd && store_lane) {
             const long c = (long)(r - 2) * si + (long)J * sj;
