@@ -523,9 +523,18 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         iso_row_leaves(pb, gxb, sxx, sxy, quarter, pmx, txx, txy);
         enter(pn);
         __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
+#if defined(SFHIP_DIAG_NO_STORE)  // diagnosis builds only: what the stores cost
+        if (upd && store_lane && out[0] < -1e300) {
+#else
         if (upd && store_lane) {
+#endif
+#if defined(SFHIP_DIAG_PLANAR_STORE)  // diagnosis builds only (WRONG results): the same bytes, 512 contiguous bytes per instruction
+            const long c = (long)(r - 2) * si + (long)(J - lane) * sj + lane;
+            pwr[c] = out[0]; pwr[c + 64] = out[1]; pwr[c + 128] = out[2];
+#else
             const long c = (long)(r - 2) * si + (long)J * sj;
             pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2];
+#endif
         }
     }
     if (WS) {
