@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
             pwr[c] = out[0]; pwr[c + 64] = out[1]; pwr[c + 128] = out[2];
 #else
             const long c = (long)(r - 2) * si + (long)J * sj;
+            // (non-temporal stores were measured: -1.5 % on the a = 0 stage alone, nothing on the RK2 pair)
             pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2];
 #endif
         }
