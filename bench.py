@@ -28,8 +28,8 @@ Output fields beyond the driver's contract
                  `traffic`: HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
                  same workload, run by this command as child processes before it touches the GPU (N = 1; 3 steps
                  each); the committed profiles/traffic.json when such a pass is not possible, with the reason
-  roofline_valu  what actually binds: the kernel's fp64 VALU instruction stream (count per launch from the
-                 committed PMC pass, profiles/valu.json) against the issue rate of 1024 SIMDs
+  roofline_valu  what actually binds: the kernel's fp64 VALU instruction stream (count per launch and the clock
+                 under the kernel from two more such passes) against the issue rate of 1024 SIMDs
   cpu_baseline   the reference's own C/OpenMP kernels (oracle/_ref, built from /root/reference by
                  oracle/build_ref.py) or, where absent, our C port (oracle/sf_oracle.c), driven in the
                  reference's order on a bounded sample of the same workload (N = 1, rank 0 only).
@@ -88,7 +88,7 @@ def parse_args():
     ap.add_argument("--strong", action="store_true",
                     help="headline = the MESH held at 4096^2 as N grows (strong scaling) instead of the zones per GPU")
     ap.add_argument("--no-traffic-pass", action="store_true",
-                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1)")
+                    help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic and roofline_valu (N = 1)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: measure the headline workload only")
     ap.add_argument("--halo-transport", default=None, choices=["torch", "rccl"],
                     help="N > 1: halo slabs and the wavespeed all-reduce through torch.distributed (default) or through "
@@ -120,59 +120,90 @@ def launch_ranks(args):
 DOMINANT_KERNEL = {"iso": "iso_stage_kernel", "gam": "gam_stage_kernel", "srhd": "srhd_march_kernel", "dg": "dg_advance_kernel"}
 
 
-def live_traffic(args, resolution):
-    """
-    HBM bytes per launch of the dominant kernel, measured now: two child runs of this file under
-    ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE: one counter block per pass), 3 steps of the same workload
-    each, started before this process has touched the GPU.  Bytes as /opt/skills/guides/MI355X_MICROARCH.md
-    prescribes for gfx950: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the kernel's launches.
-    Returns (bytes or None, how it was obtained or why not).
-    """
-    if args.no_traffic_pass:
-        return None, "--no-traffic-pass"
-    if os.environ.get("SFHIP_BENCH_CHILD"):
-        return None, "this is a counter pass itself"
-    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
-        return None, "already running under a profiler"
+def counter_pass(args, resolution, counters, steps, ramp_seconds, tmp):
+    """One child run of this file under ``rocprofv3 --pmc <counters>`` (one counter block per pass).  Returns
+    ({counter: [value per launch of the dominant kernel]}, [duration of those launches in ns]) or a reason string."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
-        return None, "rocprofv3 not found"
+        return "rocprofv3 not found"
     pattern = DOMINANT_KERNEL[args.solver]
     env = dict(os.environ, SFHIP_BENCH_CHILD="1", TMPDIR="/tmp")
-    mean = {}
+    out = os.path.join(tmp, counters[0])
+    cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.abspath(__file__), "--solver", args.solver, "--resolution", str(resolution),
+           "--steps", str(steps), "--warmup", "1", "--ramp-seconds", str(ramp_seconds), "--no-cpu-baseline", "--no-events"]
+    # a session of its own, so that a pass that hangs can be ended together with whatever it started
+    proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                            start_new_session=True)
+    try:
+        status = proc.wait(timeout=90)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.wait()
+        return f"the {counters[0]} pass did not finish within 90 s"
+    if status != 0:
+        return f"the {counters[0]} pass ended with status {status}"
+    values = {c: [] for c in counters}
+    spans = []
+    for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if pattern in row["Kernel_Name"] and row["Counter_Name"] in values:
+                    values[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    if row["Counter_Name"] == counters[0]:
+                        spans.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    if not all(values.values()):
+        return f"the {counters[0]} pass recorded no launch of {pattern}"
+    return values, spans
+
+
+def live_counters(args, resolution):
+    """
+    What the roofline objects need from the hardware counters, measured now: child runs of this file under
+    ``rocprofv3 --pmc``, started before this process has touched the GPU -- FETCH_SIZE and WRITE_SIZE (3 steps each;
+    HBM bytes per launch as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: (2 * FETCH_SIZE +
+    WRITE_SIZE) * 1024), SQ_INSTS_VALU with SQ_ACTIVE_INST_VALU (3 steps: instructions per launch, cycles each) and
+    GRBM_GUI_ACTIVE (40 steps after 0.3 s of load: the clock under the kernel = counter / 8 XCDs / duration, upper
+    half of the launches).  Returns {"traffic": (bytes | None, note), "valu": (dict | None, note)}.
+    """
+    why = None
+    if args.no_traffic_pass:
+        why = "--no-traffic-pass"
+    elif os.environ.get("SFHIP_BENCH_CHILD"):
+        why = "this is a counter pass itself"
+    elif "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        why = "already running under a profiler"
+    if why:
+        return {"traffic": (None, why), "valu": (None, why)}
+    result = {}
     tmp = tempfile.mkdtemp(prefix="sfhip_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
-                   sys.executable, os.path.abspath(__file__), "--solver", args.solver, "--resolution", str(resolution),
-                   "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline", "--no-events"]
-            # a session of its own, so that a pass that hangs can be ended together with whatever it started
-            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                    start_new_session=True)
-            try:
-                status = proc.wait(timeout=90)
-            except subprocess.TimeoutExpired:
-                os.killpg(proc.pid, signal.SIGKILL)
-                proc.wait()
-                return None, f"the {counter} pass did not finish within 90 s"
-            if status != 0:
-                return None, f"the {counter} pass ended with status {status}"
-            values = []
-            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if pattern in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            values.append(float(row["Counter_Value"]))
-            if not values:
-                return None, f"the {counter} pass recorded no launch of {pattern}"
-            mean[counter] = sum(values) / len(values)
-            launches = len(values)
+        fetch = counter_pass(args, resolution, ["FETCH_SIZE"], 3, 0, tmp)
+        write = counter_pass(args, resolution, ["WRITE_SIZE"], 3, 0, tmp) if not isinstance(fetch, str) else fetch
+        if isinstance(fetch, str) or isinstance(write, str):
+            result["traffic"] = (None, fetch if isinstance(fetch, str) else write)
+        else:
+            f, w = fetch[0]["FETCH_SIZE"], write[0]["WRITE_SIZE"]
+            result["traffic"] = (round((2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0),
+                                 "measured by this command: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of "
+                                 f"the same workload (3 steps, {len(f)} launches each), (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
+                                 "per launch")
+        sq = counter_pass(args, resolution, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"], 3, 0, tmp)
+        clock = counter_pass(args, resolution, ["GRBM_GUI_ACTIVE"], 40, 0.3, tmp) if not isinstance(sq, str) else sq
+        if isinstance(sq, str) or isinstance(clock, str):
+            result["valu"] = (None, sq if isinstance(sq, str) else clock)
+        else:
+            insts, active = sq[0]["SQ_INSTS_VALU"], sq[0]["SQ_ACTIVE_INST_VALU"]
+            ghz = sorted(v / 8.0 / ns for v, ns in zip(clock[0]["GRBM_GUI_ACTIVE"], clock[1]) if ns > 0)
+            ghz = ghz[len(ghz) // 2:]  # the first launches of the pass run on the clock ramp
+            result["valu"] = (dict(insts_per_launch=round(sum(insts) / len(insts)),
+                                   cycles_per_inst=round(4.0 * sum(active) / sum(insts), 3),
+                                   clock_ghz=round(sum(ghz) / len(ghz), 3)),
+                              "measured by this command: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU (3 steps) and "
+                              f"--pmc GRBM_GUI_ACTIVE (40 steps, upper half of {len(clock[1])} launches) child passes")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return round((2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0), (
-        f"measured by this command: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of the same workload "
-        f"(3 steps, {launches} launches each), (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch")
+    return result
 
 
 def recorded(table, solver, resolution, world):
@@ -437,7 +468,11 @@ def roofline_of(args, run, world):
     roofline["traffic_note"] = traffic_source or (f"no PMC pass was recorded for {solver} at {resolution}^2 on {world} "
                                                   "GPU(s): profiles/traffic.json holds the profiled shapes")
     valu = None
-    insts = recorded("valu", solver, resolution, world)
+    insts, valu_source = run.get("live_valu", (None, None))
+    if insts is None:
+        why = valu_source
+        insts = recorded("valu", solver, resolution, world)
+        valu_source = "profiles/valu.json (committed PMC passes of this shape)" + (f"; no live pass: {why}" if why else "")
     if insts:
         clock_ghz = insts.get("clock_ghz", 2.1)
         count = insts["insts_per_launch"]  # SQ_INSTS_VALU per launch, averaged over the step's launches
@@ -447,9 +482,10 @@ def roofline_of(args, run, world):
             bound="valu", achieved=round(rate / 1e9, 1), peak=round(peak / 1e9, 1), unit="G wave-instructions/s",
             frac=round(rate / peak, 4), insts_per_launch=count, cycles_per_instruction=insts.get("cycles_per_inst"),
             clock_ghz=clock_ghz,
-            note="SQ_INSTS_VALU per launch from the committed PMC pass (profiles/valu.json) / this run's launch "
-                 "duration, against 1024 SIMDs x clock / 4 cycles per wave64 fp64 instruction; the clock is the "
-                 "one measured under this kernel in that pass (GRBM_GUI_ACTIVE / wall)",
+            note="SQ_INSTS_VALU per launch / this run's launch duration, against 1024 SIMDs x clock / 4 cycles per "
+                 "wave64 fp64 instruction; the clock is the one measured under this kernel (GRBM_GUI_ACTIVE / 8 / "
+                 "duration)",
+            counters=valu_source,
         )
     kernel_ms = {name + "_ms": round(v[0] / v[1], 4) for name, v in per_kernel.items()}
     return roofline, valu, kernel_ms
@@ -490,10 +526,14 @@ def main():
 
     use_events = not args.no_events and not args.unfused
     # the counter passes are child processes: they come first, while this process has not touched the GPU
-    traffic_now = live_traffic(args, resolution) if world == 1 and use_events else (None, "N > 1" if world > 1 else None)
+    if world == 1 and use_events:
+        counters_now = live_counters(args, resolution)
+    else:
+        counters_now = {"traffic": (None, "N > 1" if world > 1 else None), "valu": (None, "N > 1" if world > 1 else None)}
     ranks = Ranks(args)
     head = measure(args, ranks, args.solver, resolution, args.steps, args.warmup, use_events)
-    head["live_traffic"] = traffic_now
+    head["live_traffic"] = counters_now["traffic"]
+    head["live_valu"] = counters_now["valu"]
     bytes_per_update = 5 * 8.0 * NCONS[args.solver]
     if args.solver == "srhd":
         bytes_per_update = SRHD_BYTES_PER_ZONE_UPDATE
