@@ -55,7 +55,7 @@ for kname, counters in sorted(agg.items()):
             ghz = sum(top) / len(top)
             lines.append(f"   derived: clock under the kernel = {ghz:.3f} GHz (GRBM_GUI_ACTIVE / 8 / duration, "
                          f"upper half of {len(clocks[kname])} launches)")
-            if "dg_limit" not in kname:
+            if "dg_limit" not in kname and len(clocks[kname]) >= 10:  # (a variant launched once, on the ramp, says nothing)
                 valu_clock.append(ghz)
         if "SQ_ACTIVE_INST_VALU" in mean and "SQ_INSTS_VALU" in mean:
             lines.append(f"   derived: cycles per VALU instruction = {4 * mean['SQ_ACTIVE_INST_VALU'] / mean['SQ_INSTS_VALU']:.2f}")
