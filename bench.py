@@ -120,7 +120,7 @@ def launch_ranks(args):
 DOMINANT_KERNEL = {"iso": "iso_stage_kernel", "gam": "gam_stage_kernel", "srhd": "srhd_march_kernel", "dg": "dg_advance_kernel"}
 
 
-def counter_pass(args, resolution, counters, steps, ramp_seconds, tmp):
+def counter_pass(args, resolution, counters, steps, ramp_seconds, tmp, limit=90):
     """One child run of this file under ``rocprofv3 --pmc <counters>`` (one counter block per pass).  Returns
     ({counter: [value per launch of the dominant kernel]}, [duration of those launches in ns]) or a reason string."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -136,11 +136,11 @@ def counter_pass(args, resolution, counters, steps, ramp_seconds, tmp):
     proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                             start_new_session=True)
     try:
-        status = proc.wait(timeout=90)
+        status = proc.wait(timeout=limit)
     except subprocess.TimeoutExpired:
         os.killpg(proc.pid, signal.SIGKILL)
         proc.wait()
-        return f"the {counters[0]} pass did not finish within 90 s"
+        return f"the {counters[0]} pass did not finish within {limit} s"
     if status != 0:
         return f"the {counters[0]} pass ended with status {status}"
     values = {c: [] for c in counters}
@@ -178,8 +178,14 @@ def live_counters(args, resolution):
     result = {}
     tmp = tempfile.mkdtemp(prefix="sfhip_pmc_", dir="/tmp")
     try:
-        fetch = counter_pass(args, resolution, ["FETCH_SIZE"], 3, 0, tmp)
-        write = counter_pass(args, resolution, ["WRITE_SIZE"], 3, 0, tmp) if not isinstance(fetch, str) else fetch
+        # (the first import of torch on a fresh box can take a minute or two: the first pass gets that long; a pass
+        # that fails or hangs ends the series, so that a broken profiler costs minutes at most)
+        fetch = counter_pass(args, resolution, ["FETCH_SIZE"], 3, 0, tmp, limit=240)
+        if isinstance(fetch, str):
+            return {"traffic": (None, fetch), "valu": (None, fetch)}
+        write = counter_pass(args, resolution, ["WRITE_SIZE"], 3, 0, tmp)
+        if isinstance(write, str):
+            return {"traffic": (None, write), "valu": (None, write)}
         if isinstance(fetch, str) or isinstance(write, str):
             result["traffic"] = (None, fetch if isinstance(fetch, str) else write)
         else:
