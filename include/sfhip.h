@@ -635,9 +635,9 @@ SFHIP_API int sfhip_reductions_workspace_len(
  *               sink_radius, sink_model of mass 1, then of mass 2, at the stage time;
  *   next_masses  8 doubles: x, y, mass, softening_length of the two masses at the time
  *               the output state belongs to (cbdiso_2d with want_wavespeed; else NULL).
- * A plan also owns 8 bytes of pinned host memory, a stream and two events for reading
- * the reduced wavespeed back (sfhip_plan_fetch_begin / _wait) without torch's stream
- * bookkeeping; these are created with the plan -- the per-step calls allocate nothing.
+ * A plan also owns 64 bytes of pinned host memory through which a stage hands the reduced
+ * wavespeed to the host (sfhip_plan_host_wait); it is allocated with the plan -- the
+ * per-step calls allocate nothing.
  * create returns a plan id >= 0, or -1 (sfhip_last_error); the others 0 or an error.
  * compute_stream / side_stream: hipStream_t the launches go to (on_side_stream 0 / 1).
  */
@@ -659,8 +659,6 @@ int sfhip_plan_stage(int plan, const double *masses, const double *next_masses,
                      int i_begin, int i_end, int want_wavespeed, double wavespeed_floor, double *wavespeed_max,
                      double *amax_device, double dt_dx, double dt_cfl, double *zero_slot, int on_side_stream,
                      double host_seq);
-int sfhip_plan_fetch_begin(int plan, const double *device_scalar);
-int sfhip_plan_fetch_wait(int plan, double *host_value);
 /* host_seq != 0 (needs amax_device): as soon as the launch starts on the device one lane writes
  * *amax_device and then host_seq to the plan's pinned memory, and sfhip_plan_host_wait(plan, host_seq, &v)
  * returns that value: the host learns the reduced wavespeed without a copy or an event in the stream. */

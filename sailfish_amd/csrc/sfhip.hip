@@ -696,9 +696,8 @@ struct StagePlan {
     double gamma = 0, alpha = 0, cooling = 0, mach_ceiling = 0, pfloor = 0;
     int constant_softening = 0;
     int clamp_ilo = 0, clamp_ihi = 0;
-    hipStream_t compute = nullptr, side = nullptr, fetch = nullptr;
-    hipEvent_t ready = nullptr, done = nullptr;
-    double *pinned = nullptr;     // host view: [0] fetched value; [2] value and [3] sequence number written by a stage
+    hipStream_t compute = nullptr, side = nullptr;
+    double *pinned = nullptr;     // host view: [2] value and [3] sequence number written by a stage
     double *pinned_dev = nullptr; // device view of the same memory
     // sfhip_plan_step_rk2's host time by phase, accumulated (ns): stage-0 launch, wait for the hand-over,
     // dt + orbit, stage-1 launch; and the number of steps (sfhip_plan_step_timing)
@@ -727,9 +726,6 @@ int plan_alloc(StagePlan **out)
             StagePlan &pl = g_plans[id];
             pl = StagePlan();
             hipError_t e = hipGetDevice(&pl.device);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl.fetch, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&pl.ready, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&pl.done, hipEventDisableTiming);
             if (e == hipSuccess) e = hipHostMalloc((void **)&pl.pinned, 8 * sizeof(double), hipHostMallocDefault);
             if (e == hipSuccess) {
                 memset(pl.pinned, 0, 8 * sizeof(double));
@@ -737,9 +733,6 @@ int plan_alloc(StagePlan **out)
             }
             if (e != hipSuccess) {
                 if (pl.pinned) (void)hipHostFree(pl.pinned);
-                if (pl.done) (void)hipEventDestroy(pl.done);
-                if (pl.ready) (void)hipEventDestroy(pl.ready);
-                if (pl.fetch) (void)hipStreamDestroy(pl.fetch);
                 pl = StagePlan();
                 fail((int)e, hipGetErrorString(e));
                 return -1;
@@ -822,11 +815,7 @@ int sfhip_plan_destroy(int plan)
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     StagePlan *pl = plan_of(plan);
     if (!pl) return -1;
-    (void)hipEventSynchronize(pl->done);
     (void)hipHostFree(pl->pinned);
-    (void)hipEventDestroy(pl->done);
-    (void)hipEventDestroy(pl->ready);
-    (void)hipStreamDestroy(pl->fetch);
     *pl = StagePlan();
     return 0;
 }
@@ -885,30 +874,6 @@ int sfhip_plan_stage(int plan, const double *masses, const double *next_masses,
     }
     t_stream = saved;
     return rc;
-}
-
-// Start copying one device double to the plan's pinned host word on the plan's own stream, ordered behind
-// everything queued on the compute stream so far and nothing queued later.
-int sfhip_plan_fetch_begin(int plan, const double *device_scalar)
-{
-    StagePlan *pl = plan_of(plan);
-    if (!pl || !device_scalar) return pl ? fail(-1, "sfhip_plan_fetch_begin: null pointer") : -1;
-    hipError_t e = hipEventRecord(pl->ready, pl->compute);
-    if (e == hipSuccess) e = hipStreamWaitEvent(pl->fetch, pl->ready, 0);
-    if (e == hipSuccess) e = hipMemcpyAsync(pl->pinned, device_scalar, sizeof(double), hipMemcpyDeviceToHost, pl->fetch);
-    if (e == hipSuccess) e = hipEventRecord(pl->done, pl->fetch);
-    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
-}
-
-// Block until the copy started by sfhip_plan_fetch_begin has arrived; the value goes to *host_value.
-int sfhip_plan_fetch_wait(int plan, double *host_value)
-{
-    StagePlan *pl = plan_of(plan);
-    if (!pl || !host_value) return pl ? fail(-1, "sfhip_plan_fetch_wait: null pointer") : -1;
-    hipError_t e = hipEventSynchronize(pl->done);
-    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    *host_value = *pl->pinned;
-    return 0;
 }
 
 // ---------------------------------------------------------------------------

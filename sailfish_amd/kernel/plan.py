@@ -30,10 +30,7 @@ def _bind(module):
     module.sfhip_plan_step_timing.argtypes = [i, _c_double_p]
     module.sfhip_plan_step_timing.restype = i
     module.sfhip_kepler_orbital_state.restype = i
-    module.sfhip_plan_fetch_begin.argtypes = [i, p]
-    module.sfhip_plan_fetch_wait.argtypes = [i, _c_double_p]
-    for name in ("create_cbdiso_2d", "create_cbdgam_2d", "set_side_stream", "destroy", "stage", "fetch_begin",
-                 "fetch_wait", "host_wait"):
+    for name in ("create_cbdiso_2d", "create_cbdgam_2d", "set_side_stream", "destroy", "stage", "host_wait"):
         getattr(module, "sfhip_plan_" + name).restype = i
     module._sfhip_plan_bound = True
 
@@ -135,11 +132,3 @@ class StagePlan:
             raise self._error(f"sfhip_plan_host_wait failed: {self.lib.last_error()}")
         return self._host_value.value
 
-    def fetch_begin(self, scalar):
-        if self.module.sfhip_plan_fetch_begin(self.id, scalar.data_ptr()) != 0:
-            raise self._error(f"sfhip_plan_fetch_begin failed: {self.lib.last_error()}")
-
-    def fetch_wait(self):
-        if self.module.sfhip_plan_fetch_wait(self.id, self._host_ref) != 0:
-            raise self._error(f"sfhip_plan_fetch_wait failed: {self.lib.last_error()}")
-        return self._host_value.value

@@ -801,10 +801,6 @@ class SolverBase:
         """
         if self.backend.mode != "hip":
             return lambda: float(scalar.item())
-        plan = getattr(self.patches[0], "plan", None)  # (the cbdisodg_2d patches have none)
-        if plan is not None:  # pinned word, stream and events owned by the plan: two C calls, no torch bookkeeping
-            plan.fetch_begin(scalar)
-            return plan.fetch_wait
         torch = self._torch()
         if self._fetch_stream is None:
             self._fetch_stream = torch.cuda.Stream()

@@ -75,8 +75,7 @@ def test_library_exports_every_declared_symbol():
     for name in list(api) + ["sfhip_set_device", "sfhip_device_count", "sfhip_set_stream", "sfhip_synchronize",
                              "sfhip_last_error", "sfhip_selftest_lane_shift",
                              "sfhip_plan_create_cbdiso_2d", "sfhip_plan_create_cbdgam_2d", "sfhip_plan_set_side_stream",
-                             "sfhip_plan_destroy", "sfhip_plan_stage", "sfhip_plan_fetch_begin",
-                             "sfhip_plan_fetch_wait", "sfhip_plan_host_wait", "sfhip_plan_step_rk2", "sfhip_plan_step_timing",
+                             "sfhip_plan_destroy", "sfhip_plan_stage", "sfhip_plan_host_wait", "sfhip_plan_step_rk2", "sfhip_plan_step_timing",
                              "sfhip_kepler_orbital_state"]:
         assert name in exported, name
 
