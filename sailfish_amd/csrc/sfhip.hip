@@ -967,6 +967,9 @@ int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_cur
     result3[0] = amax;
     if (amax < wavespeed_floor) return 1;
     const double dt = dx / amax * cfl;                                  // driver.py:509-510
+    // A blown-up state (NaN wavespeed): the reference fails in the Kepler solve of the next stage time (floor of a
+    // NaN, kepler.py:356-366).  Nothing more is launched; the caller raises that error.
+    if (!(dt == dt)) return 2;
     const double time0 = time;
     const double t1 = time0 * 0.0 + (time + dt) * (1.0 - 0.0);          // cbdiso_2d.py:239 after stage 0
     const double t2 = time0 * 0.5 + (t1 + dt) * (1.0 - 0.5);            // ... after stage 1

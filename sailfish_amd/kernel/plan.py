@@ -114,9 +114,11 @@ class StagePlan:
         """One whole RK2 step (sfhip_plan_step_rk2).  Returns (redo, amax, dt, time_after)."""
         status = self._step(self.id, state.data_ptr(), other.data_ptr(), slot_current.data_ptr(), slot_next.data_ptr(),
                             dx, cfl, time, self._elements, self._shared, wavespeed_floor, floor_fraction, host_seq, self._result)
-        if status not in (0, 1):
+        if status not in (0, 1, 2):
             raise self._error(f"sfhip_plan_step_rk2 failed ({status}): {self.lib.last_error()}")
         r = self._result
+        if status == 2:  # NaN wavespeed: dt and the time after the step are NaN, stage 1 was not launched
+            return False, r[0], float("nan"), float("nan")
         return status == 1, r[0], r[1], r[2]
 
     def step_timing(self):

@@ -746,11 +746,15 @@ class SolverBase:
                     self._slot_valid = False
                     self.wavespeed_redos += 1
                     continue
+                if dt != dt:
+                    # the run has blown up (NaN wavespeed): fail where and how the Python stages and the reference
+                    # do, in the Kepler solve of the next stage time (kepler.py:356-366: floor of a NaN)
+                    self.point_masses(p0.stage_time(0.0, dt))
                 self._wavespeed_floor = WAVESPEED_FLOOR_FRACTION * amax
                 p0.time0 = p0.time
                 p0.time = p0.stage_time(0.0, dt)
                 p0.time = p0.stage_time(0.5, dt)  # (the buffers swap twice: the state is where it was)
-                if p0.time != t_after:
+                if p0.time != t_after and not (p0.time != p0.time and t_after != t_after):  # (a NaN dt gives NaN twice)
                     raise RuntimeError(f"sfhip_plan_step_rk2 and Patch.stage_time disagree: {t_after!r} != {p0.time!r}")
                 p0.wavespeed_valid = False
                 self._slot_cur = 1 - self._slot_cur

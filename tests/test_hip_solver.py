@@ -283,3 +283,28 @@ def test_wavespeed_filter_fraction_does_not_change_the_bits(model, monkeypatch):
     assert redos[0] == 0 and redos[2] > 0, redos  # the highest bar is missed whenever the maximum falls at all
     for other in runs[1:]:
         assert other[0] == runs[0][0] and other[1] == runs[0][1] and np.array_equal(other[2], runs[0][2])
+
+
+@pytest.mark.parametrize("model", [{}, dict(eos="gamma-law")], ids=["iso", "gam"])
+@pytest.mark.parametrize("no_c_step", ["", "1"], ids=["one-call", "python-stages"])
+def test_blown_up_state_kills_dt_not_the_process(no_c_step, model, monkeypatch):
+    """A NaN in the state must end in a dt that visibly dies, as in the reference, not in a finite-looking one or an
+    exception of the step's own making.  cbdgam: the NaN energy stays a NaN pressure (`max2(floor, p)`), reaches the
+    wavespeed fold, the next dt is NaN and the step fails where the reference's does.  cbdiso: the reference's recovery turns the NaN zone into floor density
+    at ceiling velocity (cbdiso_2d.c:268-283), so the wavespeed jumps to the velocity ceiling and dt collapses."""
+    import math
+
+    monkeypatch.setenv("SFHIP_NO_C_STEP", no_c_step)
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(64)
+    s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, mode="hip")
+    healthy = s.step(s.recommended_cfl)
+    assert math.isfinite(healthy)
+    s.patches[0].primitive1[20, 30, 0] = float("nan")
+    assert math.isfinite(s.step(s.recommended_cfl))  # formed from the wavespeed of the state before the NaN appeared
+    if model:
+        # dt is NaN now; the step ends as the reference's advance(dt) does: floor(NaN) in the Kepler solve of stage 1's time
+        with pytest.raises(ValueError, match="NaN"):
+            s.step(s.recommended_cfl)
+    else:
+        assert s.step(s.recommended_cfl) < 1e-6 * healthy and s.step(s.recommended_cfl) < 1e-6 * healthy
