@@ -33,6 +33,9 @@ Fixtures:
   gam_disk_64.npz       gamma-law disk 64^2, 20 steps (alpha viscosity, buffer)
   gam_cooling_48.npz    gamma-law with cooling 1e-2, 48^2, 10 steps
   gam_explosion_64.npz  gamma-law explosion 64^2, 20 steps
+  iso_disk_96_developed.npz, gam_disk_96_developed.npz
+                        20 steps of a DEVELOPED disk at 96^2: the reference runs 1500 steps, a second reference solver
+                        is started from that solution and time (as from a checkpoint) and recorded
   srhd_uniform_polar.npz        uniform-polar, 20 zones per decade, 10 RK2 steps (geometrical source terms)
   srhd_envelope_shock_p3.npz    envelope-shock (u_shell 30), expanding polar mesh, 3 patches, wavespeed-based dt
   srhd_envelope_jet_p2.npz      envelope-shock with the jet inflow boundary, 2 patches (first-order zones)
@@ -93,13 +96,24 @@ def reference_modules():
 
 
 def run_reference(SetupBase, make_solver, setup_name, resolution, steps, model=None, options=None,
-                  num_patches=1, cfl=None):
+                  num_patches=1, cfl=None, spinup=0):
+    """`spinup` > 0: the recorded run starts from a DEVELOPED flow -- the reference runs that many steps first, and
+    a second reference solver is then started from the resulting solution and time exactly as the driver restarts
+    from a checkpoint (driver.py:439-449); `initial` and `time0` are what that solver was given."""
     setup = SetupBase.find_setup_class(setup_name)(**(model or {}))
     mesh = setup.mesh(resolution)
     solver = make_solver(setup.solver, setup.physics, options or {}, setup=setup, mesh=mesh,
                          time=setup.start_time, solution=None, num_patches=num_patches, mode="cpu")
-    initial = solver.solution.copy()
     cfl = cfl or solver.recommended_cfl
+    time0 = None
+    if spinup:
+        for _ in range(spinup):
+            solver.advance(mesh.min_spacing(solver.time) / solver.maximum_wavespeed() * cfl)
+        developed, time0 = solver.solution.copy(), solver.time
+        assert np.isfinite(developed).all()
+        solver = make_solver(setup.solver, setup.physics, options or {}, setup=setup, mesh=mesh,
+                             time=time0, solution=developed, num_patches=num_patches, mode="cpu")
+    initial = solver.solution.copy()
     dts, times = [], []
     for _ in range(steps):
         # driver.py:508-512
@@ -108,8 +122,11 @@ def run_reference(SetupBase, make_solver, setup_name, resolution, steps, model=N
         solver.advance(dt)
         dts.append(dt)
         times.append(solver.time)
-    return dict(initial=initial, final=solver.solution.copy(), dt=np.array(dts), time=np.array(times),
-                cfl=np.array(cfl), resolution=np.array(resolution), num_patches=np.array(num_patches))
+    out = dict(initial=initial, final=solver.solution.copy(), dt=np.array(dts), time=np.array(times),
+               cfl=np.array(cfl), resolution=np.array(resolution), num_patches=np.array(num_patches))
+    if time0 is not None:
+        out["time0"] = np.array(time0)
+    return out
 
 
 ISO_DIAGNOSTICS = [
@@ -217,6 +234,9 @@ def main():
         "gam_disk_64": run("circumbinary-disk", 64, 20, model=dict(eos="gamma-law")),
         "gam_cooling_48": run("circumbinary-disk", 48, 10, model=dict(eos="gamma-law", cooling_coefficient=1e-2)),
         "gam_explosion_64": run("cylindrical-explosion", 64, 20, model=dict(eos="gamma-law")),
+        # developed flows (spiral shocks, streams into the sinks, the buffer at work), restarted as from a checkpoint
+        "iso_disk_96_developed": run("circumbinary-disk", 96, 20, spinup=1500),
+        "gam_disk_96_developed": run("circumbinary-disk", 96, 20, model=dict(eos="gamma-law"), spinup=1500, num_patches=2),
     }
     out["iso_reductions_64_p2"] = run_reductions(SetupBase, make_solver, 64, 12, ISO_DIAGNOSTICS,
                                                  model=dict(eccentricity=0.2, mass_ratio=0.5, domain_radius=3.0, sink_radius=0.1),
@@ -240,11 +260,15 @@ def main():
     out["dg_explosion_40_nolimit"] = dg("cylindrical-explosion", 40, 12, model=dict(use_dg=True),
                                         options=dict(limit_slopes=False), num_patches=2)
     out["dg_explosion_40"] = dg("cylindrical-explosion", 40, 12, model=dict(use_dg=True))
+    only = set(sys.argv[1:])  # names given on the command line: write those fixtures only (the others are left as they are)
     for name, data in out.items():
+        if only and name not in only:
+            continue
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
         print(name, data["final"].shape if "final" in data else data["values"][:3],
               "t_end", data["time"][-1] if data["time"].ndim else float(data["time"]), flush=True)
-    np.savez_compressed(os.path.join(HERE, "kepler.npz"), rows=kepler_fixture(SetupBase))
+    if not only or "kepler" in only:
+        np.savez_compressed(os.path.join(HERE, "kepler.npz"), rows=kepler_fixture(SetupBase))
     # one-patch == four-patch bitwise for the power-of-two mesh (recorded, then relied upon by tests)
     one = run("circumbinary-disk", 128, 20, num_patches=1)
     assert np.array_equal(one["final"], out["iso_disk_128_p4"]["final"])

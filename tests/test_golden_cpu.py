@@ -27,7 +27,18 @@ CASES = {
     "gam_disk_64": ("circumbinary-disk", dict(eos="gamma-law"), {}),
     "gam_cooling_48": ("circumbinary-disk", dict(eos="gamma-law", cooling_coefficient=1e-2), {}),
     "gam_explosion_64": ("cylindrical-explosion", dict(eos="gamma-law"), {}),
+    # developed flows: the fixture's `initial` is the reference's state after 1500 steps, restarted as from a checkpoint
+    "iso_disk_96_developed": ("circumbinary-disk", {}, {}),
+    "gam_disk_96_developed": ("circumbinary-disk", dict(eos="gamma-law"), {}),
 }
+
+
+def start_of(g):
+    """(time, solution) a solver is to be started with: the analytic initial data at t = 0 (solution None), or the
+    developed state and time a fixture recorded."""
+    if "time0" in g.files:
+        return float(g["time0"]), g["initial"]
+    return 0.0, None
 
 
 def load(name):
@@ -40,7 +51,9 @@ def test_oracle_solver_reproduces_reference_run_bitwise(name):
     g = load(name)
     setup = make_setup(setup_name, **model)
     mesh = setup.mesh(int(g["resolution"]))
-    s = ref_solver.OracleSolver(setup, mesh, time=0.0, num_patches=int(g["num_patches"]), options=options)
+    time0, solution = start_of(g)
+    s = ref_solver.OracleSolver(setup, mesh, time=time0, num_patches=int(g["num_patches"]), options=options,
+                                solution=solution)
     assert np.array_equal(s.solution, g["initial"])
     cfl = float(g["cfl"])
     for dt_ref, t_ref in zip(g["dt"], g["time"]):
