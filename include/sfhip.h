@@ -674,7 +674,8 @@ int sfhip_plan_host_wait(int plan, double host_seq, double *host_value);
  * result3 (host) receives amax, dt and the time after the step.  Returns 1 when amax is below
  * wavespeed_floor (only stage 0 was launched; the caller recomputes the wavespeed exactly and repeats), 2 when
  * the wavespeed and with it dt is NaN (only stage 0 was launched; the reference fails at this point, in the Kepler
- * solve of the next stage time).
+ * solve of the next stage time).  Failures are negative (-1 for bad arguments, minus the hipError_t of a failed
+ * launch), so that they cannot be taken for one of these outcomes.
  * Stage 1's epilogue evaluates exactly the zones that reach floor_fraction * amax (the caller's next
  * wavespeed_floor): any value in [0, 1) gives the same bits, higher is faster until steps start to repeat. */
 int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,

@@ -941,6 +941,10 @@ int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double 
 // shared4: softening length, sink rate, sink radius, sink model.  result3 (host): amax, dt, the time after the
 // step.  Returns 0; 1 when amax came out below wavespeed_floor (only stage 0 has been launched: the caller
 // recomputes the wavespeed exactly and redoes the step); < 0 or a HIP error code on failure.
+// sfhip_plan_step_rk2 returns 1 and 2 as outcomes (repeat the step, NaN wavespeed): a failure underneath -- a
+// hipError_t, which is positive and can be 1 or 2 -- must not be mistaken for one.
+static int step_failure(int rc) { return rc > 0 ? -rc : rc; }
+
 int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,
                         double dx, double cfl, double time, const double *elements4, const double *shared4,
                         double wavespeed_floor, double floor_fraction, double host_seq, double *result3)
@@ -958,11 +962,11 @@ int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_cur
     // stage 0 (a = 0): p^n -> other; dt from the device slot
     int rc = sfhip_plan_stage(plan, masses, nullptr, nullptr, state, other, 0.0, NAN, 0, pl->ni, 0, 0.0, nullptr,
                               slot_current, dx, cfl, slot_next, 0, host_seq);
-    if (rc) return rc;
+    if (rc) return step_failure(rc);
     const auto c1 = clock::now();
     double amax = 0.0;
     rc = sfhip_plan_host_wait(plan, host_seq, &amax);
-    if (rc) return rc;
+    if (rc) return step_failure(rc);
     const auto c2 = clock::now();
     result3[0] = amax;
     if (amax < wavespeed_floor) return 1;
@@ -986,7 +990,7 @@ int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_cur
     // stage 1 (a = 1/2): other -> state in place over p^n (u^n recomputed from it), wavespeed folded into the next slot
     rc = sfhip_plan_stage(plan, masses, next8, state, other, state, 0.5, dt, 0, pl->ni, 1, floor_fraction * amax, slot_next,
                           nullptr, 0.0, 0.0, nullptr, 0, 0.0);
-    if (rc) return rc;
+    if (rc) return step_failure(rc);
     const auto c4 = clock::now();
     pl->phase_ns[0] += std::chrono::duration<double, std::nano>(c1 - c0).count();
     pl->phase_ns[1] += std::chrono::duration<double, std::nano>(c2 - c1).count();
