@@ -934,17 +934,18 @@ int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double 
     return 0;
 }
 
+// sfhip_plan_step_rk2 returns 1 and 2 as outcomes (repeat the step, NaN wavespeed): a failure underneath -- a
+// hipError_t, which is positive and can be 1 or 2 -- must not be mistaken for one.
+static int step_failure(int rc) { return rc > 0 ? -rc : rc; }
+
 // One RK2 step of a one-patch solver whose point masses are a Kepler binary: stage 0 (dt formed in the kernel from
 // *slot_current, *slot_next zeroed, reduced wavespeed handed to the host), dt = dx / amax * cfl on the host, the
 // orbit at the stage time, stage 1 with the wavespeed fold into *slot_next.  `state` holds p^n and receives the
 // new state; `other` is the second buffer.  elements4: semimajor axis, total mass, mass ratio, eccentricity;
 // shared4: softening length, sink rate, sink radius, sink model.  result3 (host): amax, dt, the time after the
 // step.  Returns 0; 1 when amax came out below wavespeed_floor (only stage 0 has been launched: the caller
-// recomputes the wavespeed exactly and redoes the step); < 0 or a HIP error code on failure.
-// sfhip_plan_step_rk2 returns 1 and 2 as outcomes (repeat the step, NaN wavespeed): a failure underneath -- a
-// hipError_t, which is positive and can be 1 or 2 -- must not be mistaken for one.
-static int step_failure(int rc) { return rc > 0 ? -rc : rc; }
-
+// recomputes the wavespeed exactly and redoes the step); 2 when amax is NaN (likewise only stage 0: the caller
+// fails as the reference does); negative on failure.
 int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_current, double *slot_next,
                         double dx, double cfl, double time, const double *elements4, const double *shared4,
                         double wavespeed_floor, double floor_fraction, double host_seq, double *result3)
