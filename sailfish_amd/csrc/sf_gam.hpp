@@ -214,9 +214,12 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
     fr[1 + DIR] += pp[3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) du[q] = ul[q] - ur[q];
+    // min(vl - cs, vr - cs) = min(vl, vr) - cs exactly (rounding is monotone): the extremes of the two normal
+    // velocities are formed once per face, each flux subtracts / adds its own sound speed
+    const double vmin = __builtin_fmin(vl, vr), vmax = __builtin_fmax(vl, vr);
     {
-        double am = __builtin_fmin(0.0, __builtin_fmin(vl - csL, vr - csL));
-        double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csL, vr + csL));
+        double am = __builtin_fmin(0.0, vmin - csL);
+        double ap = __builtin_fmax(0.0, vmax + csL);
         // (Fl ap - Fr am - dU ap am) / (ap - am) with the three weights formed once per flux
         double rden = fast_rcp(ap - am);
         double wl = ap * rden, wr = am * rden, wd = wl * am;
@@ -224,8 +227,8 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
         for (int q = 0; q < 4; ++q) fR[q] = fl[q] * wl - fr[q] * wr - du[q] * wd;
     }
     {
-        double am = __builtin_fmin(0.0, __builtin_fmin(vl - csR, vr - csR));
-        double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csR, vr + csR));
+        double am = __builtin_fmin(0.0, vmin - csR);
+        double ap = __builtin_fmax(0.0, vmax + csR);
         double rden = fast_rcp(ap - am);
         double wl = ap * rden, wr = am * rden, wd = wl * am;
 #pragma unroll

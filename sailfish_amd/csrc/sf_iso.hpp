@@ -129,8 +129,9 @@ __device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, dou
     double fl2 = vl * ul2, fr2 = vr * ur2;
     if (DIR == 0) { fl1 += prl; fr1 += prr; }
     else          { fl2 += prl; fr2 += prr; }
-    double am = __builtin_fmin(0.0, __builtin_fmin(vl - cs, vr - cs));
-    double ap = __builtin_fmax(0.0, __builtin_fmax(vl + cs, vr + cs));
+    // min(vl - cs, vr - cs) = min(vl, vr) - cs exactly (rounding is monotone): one subtraction instead of two
+    double am = __builtin_fmin(0.0, __builtin_fmin(vl, vr) - cs);
+    double ap = __builtin_fmax(0.0, __builtin_fmax(vl, vr) + cs);
     // F = (Fl ap - Fr am - (Ul - Ur) ap am) / (ap - am) with the three weights formed once per face
     double rden = fast_rcp(ap - am);
     double wl = ap * rden, wr = am * rden, wd = wl * am;
