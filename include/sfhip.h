@@ -684,6 +684,33 @@ int sfhip_plan_step_rk2(int plan, double *state, double *other, double *slot_cur
 /* Diagnostic: mean host microseconds per sfhip_plan_step_rk2 call by phase since the last call of this function
  * (stage-0 launch, wait for the hand-over, dt + orbit, stage-1 launch) and the number of steps; out5 on the host. */
 int sfhip_plan_step_timing(int plan, double *out5);
+/* ----------------------------------------------------------------- step groups --
+ * No counterpart in the reference, whose single Python process walks over its patches and devices per stage
+ * (solvers/cbdiso_2d.py:536-586: set_bc's slice copies between patches, then one kernel call per patch;
+ * driver.py:506-512 around it).  A step group is ALL the patches one process owns (in global patch order, on
+ * one device and one compute stream) with, for either side of each patch, what lies there:
+ *     -1  the domain edge (outflow: index clamp inside the kernel),
+ *     -2  the previous / next patch of the group (a device-to-device copy of the 2-row slab),
+ *    >=0  the rank of the process that owns the neighbouring patch: the slab travels as ncclSend / ncclRecv on
+ *         `nccl_comm`, all of a stage's messages in one ncclGroup on `side_stream`, posted in the order of their
+ *         names (destination patch, lower | upper guard slab) on every rank.
+ * sfhip_step_group_rk2 is sfhip_plan_step_rk2 for the group: per stage slab copies, the rows that need no halo
+ * (compute stream), the exchange and the <= 2 + 2 rows per patch behind it (side stream, ordered by two events),
+ * and after the last stage -- with reduce_over_ranks -- ncclAllReduce(MAX) of *slot_next over the communicator,
+ * on the doubles' bit patterns as ncclUint64 (exact for non-negative values, and a NaN survives).  `state` and
+ * `other` are HOST arrays of the patches' device pointers.  Outcomes 0 / 1 / 2 and negative failures as there;
+ * *slot_current must hold the maximum over all ranks, so that every rank takes the same decisions.
+ * RCCL is bound at run time: sfhip_rccl_bind(path) dlopens the library file the communicator was made with
+ * (libsfhip.so does not link against RCCL). */
+int sfhip_rccl_bind(const char *library_path);
+int sfhip_step_group_create(int npatches, const int *plans, const int *global_ids, const int *lower, const int *upper,
+                            void *nccl_comm, int reduce_over_ranks, void *side_stream);
+int sfhip_step_group_destroy(int group);
+int sfhip_step_group_rk2(int group, double *const *state, double *const *other, double *slot_current, double *slot_next,
+                         double dx, double cfl, double time, const double *elements4, const double *shared4,
+                         double wavespeed_floor, double floor_fraction, double host_seq, double *result3);
+int sfhip_step_group_timing(int group, double *out5);
+
 /* Host only, no GPU involved: the orbital state (mass, x, y, vx, vy of body 1, then body 2) into 10 host doubles. */
 int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double mass_ratio, double eccentricity,
                                double time_since_periapse, double *out10_host);

@@ -34,6 +34,7 @@ struct GamParams {
     double mach_floor_scale;                     // 2/gamma/(gamma-1)*mach_ceiling^-2, cbdgam_2d.c:314
     int clamp_ilo, clamp_ihi, clamp_j, un_mode;
     int rows_per_chunk, i_begin, i_end, want_wavespeed;
+    int reverse;                // chunks are handed out from the last rows to the first (see launch_gam_stage)
     double ws_floor; // zones slower than this are not folded in (see include/sfhip.h)
     const double *dt_ptr;       // when set, the timestep is read from device memory instead of `dt`
     const double *amax_ptr;     // when set: dt = dt_dx / *amax_ptr * dt_cfl formed in the kernel (see IsoParams)
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
     // wave-uniform by construction: tell the compiler, so rows, branches and addresses stay scalar
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int strip = gw % nstrips;
-    const int chunk = gw / nstrips;
-    if (chunk >= nchunks) return;
+    if (gw / nstrips >= nchunks) return;
+    const int chunk = P.reverse ? nchunks - 1 - gw / nstrips : gw / nstrips;
     if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
     if (P.amax_ptr) P.dt = device_timestep(P.dt_dx, *P.amax_ptr, P.dt_cfl);
     if (gw == 0 && lane == 0) step_bookkeeping(P.zero_ptr, P.host_out, P.host_seq, P.amax_ptr);

@@ -43,6 +43,7 @@ struct IsoParams {
     int clamp_j;                // outflow in j by clamping (always true for slab decomposition)
     int un_mode;                // 0: a == 0, no u^n; 1: u^n from a conserved array; 2: u^n = p2c(p^n array)
     int rows_per_chunk;         // rows marched by one wave
+    int reverse;                // chunks are handed out from the last rows to the first (see launch_iso_stage)
     int i_begin, i_end;         // zone-row range [i_begin, i_end) to update (interior/boundary split for halo overlap)
     int want_wavespeed;         // fold max wavespeed of the OUTPUT state into *wmax
     double ws_floor;            // zones slower than this are not folded in (see include/sfhip.h)
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     // wave-uniform by construction: tell the compiler, so rows, branches and addresses stay scalar
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int strip = gw % nstrips;
-    const int chunk = gw / nstrips;
-    if (chunk >= nchunks) return; // whole wave leaves together
+    if (gw / nstrips >= nchunks) return; // whole wave leaves together
+    const int chunk = P.reverse ? nchunks - 1 - gw / nstrips : gw / nstrips;
     if (P.dt_ptr) P.dt = *P.dt_ptr; // dt computed on the device by sfhip_timestep (uniform scalar load)
     if (P.amax_ptr) P.dt = device_timestep(P.dt_dx, *P.amax_ptr, P.dt_cfl);
     if (gw == 0 && lane == 0) step_bookkeeping(P.zero_ptr, P.host_out, P.host_seq, P.amax_ptr);

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 
 #include "sf_dg.hpp"
@@ -99,6 +100,18 @@ void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
     *nchunks = (nrows + rpc - 1) / rpc;
 }
 
+// Stages with a != 0 hand their chunks out from the last rows to the first.  A stage streams 0.8-1.2 GB through the
+// 256 MB memory-side cache, which therefore ends a stage holding the rows it touched LAST; the stage that follows
+// reads the same arrays, and by starting where its predecessor stopped it finds those rows still cached (and its
+// successor, marching up again, finds what it left).  Same chunks, same bits.  Measured at 4096^2 (bench.py, A/B on
+// one box): cbdiso_2d 0.544 -> 0.533 ms per step, cbdgam_2d 0.937 -> 0.920; no effect at 2048^2 (everything is
+// cached either way) and within noise at 8192^2 (the cache holds 8 % of an array).  SFHIP_REVERSE=0 turns it off.
+bool reverse_later_stages()
+{
+    static const bool on = env_int("SFHIP_REVERSE", 1) != 0;
+    return on;
+}
+
 // waves per workgroup of the marching kernels (their launch bounds allow up to 4)
 int waves_per_block()
 {
@@ -142,6 +155,7 @@ int launch_iso_stage(sf::IsoParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+    P.reverse = P.un_mode != 0 && reverse_later_stages();
     // epilogue masses identical to the stage's (RK2's last stage): the kernel reuses the source terms' distances
     bool same = P.want_wavespeed != 0;
     for (int k = 0; k < 2 && same; ++k)
@@ -194,6 +208,7 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+    P.reverse = P.un_mode != 0 && reverse_later_stages();
     // the full-physics instantiations (see gam_stage_kernel): same formulas, flag tests resolved here
     auto active = [](const sf::Mass &m) { return m.mass > 0.0 && m.sink_model >= 1 && m.sink_model <= 3; };
     const bool full = P.alpha > 0.0 && active(P.m[0]) && active(P.m[1]) && P.buf_on && !env_int("SFHIP_GENERIC_STAGE", 0);
@@ -845,7 +860,7 @@ int sfhip_plan_stage(int plan, const double *masses, const double *next_masses,
         fill_iso(P, pl->ni, pl->nj, pl->xl, pl->xr, pl->yl, pl->yr, pl->bsd, m1.mass + m2.mass /* cbdiso_2d.py:194 */,
                  pl->brate, pl->brout, pl->bw, pl->bon, m1, m2, pl->cs2, pl->mach2, pl->eos, pl->nu, a, dt, pl->vmax,
                  pl->dfloor);
-        P.un_mode = a != 0.0 && un_source ? 2 : 0;
+        P.un_mode = a != 0.0 ? 2 : 0; // (a null un_source then fails the launch's own check)
         P.clamp_ilo = pl->clamp_ilo; P.clamp_ihi = pl->clamp_ihi; P.clamp_j = 1;
         P.i_begin = i_begin; P.i_end = i_end;
         P.want_wavespeed = want_wavespeed;
@@ -863,7 +878,7 @@ int sfhip_plan_stage(int plan, const double *masses, const double *next_masses,
         fill_gam(P, pl->ni, pl->nj, pl->xl, pl->xr, pl->yl, pl->yr, pl->gamma, pl->bsd, pl->bsp,
                  m1.mass + m2.mass /* cbdgam_2d.py:164 */, pl->brate, pl->brout, pl->bw, pl->bon, m1, m2, pl->alpha, a,
                  dt, pl->vmax, pl->cooling, pl->mach_ceiling, pl->dfloor, pl->pfloor, pl->constant_softening);
-        P.un_mode = a != 0.0 && un_source ? 2 : 0;
+        P.un_mode = a != 0.0 ? 2 : 0; // (a null un_source then fails the launch's own check)
         P.clamp_ilo = pl->clamp_ilo; P.clamp_ihi = pl->clamp_ihi; P.clamp_j = 1;
         P.i_begin = i_begin; P.i_end = i_end;
         P.want_wavespeed = want_wavespeed;
@@ -1032,6 +1047,330 @@ int sfhip_plan_host_wait(int plan, double host_seq, double *host_value)
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     *host_value = word[0];
+    return 0;
+}
+
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// Step groups: one RK2 step of ALL the patches a process owns from one call, halo exchange included.
+//
+// sfhip_plan_step_rk2 serves a solver with one patch and no neighbours.  With neighbours every stage used to go
+// through Python: two slab copies or a torch.distributed batch of sends and receives, three launches per patch,
+// the events that order the communication stream -- 0.1-0.3 ms of host time per step against 0.08 ms of kernels
+// on the 512 x 4096 slabs of BASELINE's own metric line (4096^2 over 8 GPUs).  A step group holds the patches'
+// plans in global patch order with, for either side of each, what its neighbour is: the domain edge, the next
+// patch of the group (a device-to-device slab copy) or a patch of another rank (RCCL), and performs per stage
+//     slab copies between the group's patches, event `ready`             (compute stream)
+//     the rows that need no halo, every patch                           (compute stream)
+//     wait for `ready`; one ncclGroup of all sends and receives          (side stream)
+//     the <= 2 + 2 rows per patch that need the halos                   (side stream; compute stream if no RCCL)
+//     event `joined`; the compute stream waits for it
+// which is the data flow of Solver.advance_rk (solvers/cbd_common.py), launch for launch, with the messages of a
+// group posted in the order of their names (destination patch, lower | upper guard slab) as the Python transport
+// posts them.  After the last stage the wavespeed slot is MAX-all-reduced over the ranks as ncclUint64: for
+// non-negative doubles the order of the bit patterns is the order of the values, and a NaN's pattern ranks above
+// all of them, so a blown-up rank gives every rank a NaN dt (ncclMax on ncclDouble may drop it).
+//
+// RCCL is bound at run time (sfhip_rccl_bind, dlopen of the very library file that made the communicator):
+// libsfhip.so itself does not link against it.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+} g_rccl;
+
+constexpr int NCCL_UINT64 = 5, NCCL_FLOAT64 = 8, NCCL_MAX_OP = 2; // ncclDataType_t / ncclRedOp_t (rccl.h)
+
+int rccl_fail(int status, const char *what)
+{
+    snprintf(t_error, sizeof(t_error), "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(status) : "RCCL error");
+    return -1;
+}
+
+constexpr int MAX_GROUPS = 64;
+constexpr int MAX_GROUP_PATCHES = 64;
+constexpr int PEER_EDGE = -1, PEER_LOCAL = -2;
+
+struct StepGroup {
+    int used = 0;
+    int n = 0;
+    int plans[MAX_GROUP_PATCHES];
+    int global_id[MAX_GROUP_PATCHES];
+    int lower[MAX_GROUP_PATCHES], upper[MAX_GROUP_PATCHES]; // PEER_EDGE, PEER_LOCAL or the owning rank
+    void *comm = nullptr;   // ncclComm_t, or null when no patch has a neighbour on another rank
+    int reduce_over_ranks = 0;
+    int remote = 0;         // some neighbour is reached through RCCL
+    hipStream_t compute = nullptr, side = nullptr;
+    hipEvent_t ready = nullptr, joined = nullptr;
+    double phase_ns[4] = {0, 0, 0, 0};
+    long steps_timed = 0;
+};
+
+StepGroup g_groups[MAX_GROUPS];
+
+StepGroup *group_of(int id)
+{
+    if (id < 0 || id >= MAX_GROUPS || !g_groups[id].used) {
+        fail(-1, "sfhip_step_group: no such group");
+        return nullptr;
+    }
+    return &g_groups[id];
+}
+
+struct HaloOp {
+    long name;      // 2 * destination patch + (0 lower | 1 upper guard slab)
+    int send;
+    double *ptr;
+    size_t count;
+    int peer;
+};
+
+// One RK stage of every patch of the group (see above).  rd / un / wr: per patch; un may be null (a == 0).
+int group_stage(StepGroup &G, double *const *rd, double *const *un, double *const *wr, const double *masses,
+                const double *next_masses, double a, double dt, int want_wavespeed, double wavespeed_floor,
+                double *wavespeed_max, double *amax_device, double dt_dx, double dt_cfl, double *zero_slot, double host_seq)
+{
+    StagePlan *pl[MAX_GROUP_PATCHES];
+    for (int k = 0; k < G.n; ++k)
+        if (!(pl[k] = plan_of(G.plans[k]))) return -1;
+    // halo slabs between the group's own patches (Solver.start_halo_exchange: the same-process copies)
+    for (int k = 0; k < G.n; ++k) {
+        const int nq = pl[k]->kind == 1 ? 3 : 4;
+        const size_t row = (size_t)(pl[k]->nj + 2 * sf::NG) * nq, slab = sf::NG * row * sizeof(double);
+        hipError_t e = hipSuccess;
+        if (G.lower[k] == PEER_LOCAL)
+            e = hipMemcpyAsync(rd[k], rd[k - 1] + (size_t)pl[k - 1]->ni * row, slab, hipMemcpyDeviceToDevice, G.compute);
+        if (e == hipSuccess && G.upper[k] == PEER_LOCAL)
+            e = hipMemcpyAsync(rd[k] + (size_t)(pl[k]->ni + sf::NG) * row, rd[k + 1] + (size_t)sf::NG * row, slab,
+                               hipMemcpyDeviceToDevice, G.compute);
+        if (e != hipSuccess) return fail(-(int)e, hipGetErrorString(e));
+    }
+    if (G.remote) {
+        hipError_t e = hipEventRecord(G.ready, G.compute); // everything the exchange depends on has been queued
+        if (e != hipSuccess) return fail(-(int)e, hipGetErrorString(e));
+    }
+    int lo[MAX_GROUP_PATCHES], hi[MAX_GROUP_PATCHES];
+    for (int k = 0; k < G.n; ++k) { // the rows that need no halo (queued before the transport calls: neither waits for the other)
+        const int ni = pl[k]->ni;
+        lo[k] = G.lower[k] == PEER_EDGE ? 0 : (sf::NG < ni ? sf::NG : ni);
+        hi[k] = G.upper[k] == PEER_EDGE ? ni : (ni - sf::NG > lo[k] ? ni - sf::NG : lo[k]);
+        int rc = sfhip_plan_stage(G.plans[k], masses, next_masses, un ? un[k] : nullptr, rd[k], wr[k], a, dt, lo[k], hi[k],
+                                  want_wavespeed, wavespeed_floor, wavespeed_max, amax_device, dt_dx, dt_cfl, zero_slot, 0,
+                                  k == 0 ? host_seq : 0.0);
+        if (rc) return rc > 0 ? -rc : rc;
+    }
+    if (G.remote) {
+        hipError_t e = hipStreamWaitEvent(G.side, G.ready, 0);
+        if (e != hipSuccess) return fail(-(int)e, hipGetErrorString(e));
+        HaloOp ops[4 * MAX_GROUP_PATCHES];
+        int nops = 0;
+        for (int k = 0; k < G.n; ++k) {
+            const int nq = pl[k]->kind == 1 ? 3 : 4;
+            const size_t row = (size_t)(pl[k]->nj + 2 * sf::NG) * nq, count = sf::NG * row;
+            const long id = G.global_id[k];
+            if (G.upper[k] >= 0) {
+                ops[nops++] = HaloOp{2 * (id + 1) + 0, 1, rd[k] + (size_t)pl[k]->ni * row, count, G.upper[k]};
+                ops[nops++] = HaloOp{2 * id + 1, 0, rd[k] + (size_t)(pl[k]->ni + sf::NG) * row, count, G.upper[k]};
+            }
+            if (G.lower[k] >= 0) {
+                ops[nops++] = HaloOp{2 * (id - 1) + 1, 1, rd[k] + (size_t)sf::NG * row, count, G.lower[k]};
+                ops[nops++] = HaloOp{2 * id + 0, 0, rd[k], count, G.lower[k]};
+            }
+        }
+        // between two ranks RCCL matches messages in posting order: post in the order of the names on both sides
+        for (int i = 1; i < nops; ++i)
+            for (int j = i; j > 0 && ops[j].name < ops[j - 1].name; --j) { HaloOp t = ops[j]; ops[j] = ops[j - 1]; ops[j - 1] = t; }
+        int st = g_rccl.GroupStart();
+        if (st) return rccl_fail(st, "ncclGroupStart");
+        for (int i = 0; i < nops; ++i) {
+            st = ops[i].send ? g_rccl.Send(ops[i].ptr, ops[i].count, NCCL_FLOAT64, ops[i].peer, G.comm, G.side)
+                             : g_rccl.Recv(ops[i].ptr, ops[i].count, NCCL_FLOAT64, ops[i].peer, G.comm, G.side);
+            if (st) { (void)g_rccl.GroupEnd(); return rccl_fail(st, ops[i].send ? "ncclSend" : "ncclRecv"); }
+        }
+        st = g_rccl.GroupEnd();
+        if (st) return rccl_fail(st, "ncclGroupEnd");
+    }
+    for (int k = 0; k < G.n; ++k) { // the rows behind the halos
+        const int ni = pl[k]->ni;
+        const int ranges[2][2] = {{0, lo[k]}, {hi[k], ni}};
+        for (int s = 0; s < 2; ++s) {
+            if (ranges[s][0] >= ranges[s][1]) continue;
+            int rc = sfhip_plan_stage(G.plans[k], masses, next_masses, un ? un[k] : nullptr, rd[k], wr[k], a, dt, ranges[s][0],
+                                      ranges[s][1], want_wavespeed, wavespeed_floor, wavespeed_max, amax_device, dt_dx, dt_cfl,
+                                      zero_slot, G.remote, 0.0);
+            if (rc) return rc > 0 ? -rc : rc;
+        }
+    }
+    if (G.remote) {
+        hipError_t e = hipEventRecord(G.joined, G.side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(G.compute, G.joined, 0); // the stage is complete on both streams
+        if (e != hipSuccess) return fail(-(int)e, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+// Bind the RCCL entry points the step groups call from `library_path` -- the file the caller's communicator was
+// made with (a second copy of the library would not know it).  Returns 0, or -1 (sfhip_last_error).
+int sfhip_rccl_bind(const char *library_path)
+{
+    if (!library_path) return fail(-1, "sfhip_rccl_bind: null path");
+    void *h = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        snprintf(t_error, sizeof(t_error), "sfhip_rccl_bind: %s", dlerror());
+        return -1;
+    }
+    RcclApi api;
+    api.handle = h;
+    api.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    api.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    api.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclSend");
+    api.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclRecv");
+    api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    api.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.AllReduce || !api.GetErrorString)
+        return fail(-1, "sfhip_rccl_bind: the library lacks ncclGroupStart/End, ncclSend/Recv, ncclAllReduce or ncclGetErrorString");
+    g_rccl = api;
+    return 0;
+}
+
+// npatches plans (in global patch order, all on the current device and with the same compute stream), their
+// global patch numbers, and per patch what lies below / above it: -1 the domain edge, -2 the previous / next patch
+// of this group, >= 0 the rank that owns the neighbouring patch (needs nccl_comm and sfhip_rccl_bind).
+// side_stream: where the exchange and the rows behind it run.  reduce_over_ranks: MAX-all-reduce the wavespeed
+// slot over nccl_comm after the last stage.  Returns a group id >= 0, or -1.
+int sfhip_step_group_create(int npatches, const int *plans, const int *global_ids, const int *lower, const int *upper,
+                            void *nccl_comm, int reduce_over_ranks, void *side_stream)
+{
+    if (npatches < 1 || npatches > MAX_GROUP_PATCHES || !plans || !global_ids || !lower || !upper)
+        return fail(-1, "sfhip_step_group_create: bad arguments");
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    int id = 0;
+    while (id < MAX_GROUPS && g_groups[id].used) ++id;
+    if (id == MAX_GROUPS) return fail(-1, "sfhip_step_group_create: too many groups");
+    StepGroup G;
+    G.n = npatches;
+    for (int k = 0; k < npatches; ++k) {
+        StagePlan *pl = plan_of(plans[k]);
+        if (!pl) return -1;
+        if (k == 0) G.compute = pl->compute;
+        else if (pl->compute != G.compute || pl->kind != g_plans[plans[0]].kind || pl->nj != g_plans[plans[0]].nj)
+            return fail(-1, "sfhip_step_group_create: the plans must share stream, solver and nj");
+        G.plans[k] = plans[k]; G.global_id[k] = global_ids[k]; G.lower[k] = lower[k]; G.upper[k] = upper[k];
+        if (lower[k] < PEER_LOCAL || upper[k] < PEER_LOCAL) return fail(-1, "sfhip_step_group_create: bad neighbour code");
+        if ((lower[k] == PEER_LOCAL && k == 0) || (upper[k] == PEER_LOCAL && k == npatches - 1))
+            return fail(-1, "sfhip_step_group_create: a local neighbour must be a patch of the group");
+        if (lower[k] >= 0 || upper[k] >= 0) G.remote = 1;
+        if (pl->ni < 2 * sf::NG && (lower[k] != PEER_EDGE || upper[k] != PEER_EDGE))
+            return fail(-1, "sfhip_step_group_create: a patch with neighbours needs at least 4 rows");
+    }
+    if ((G.remote || reduce_over_ranks) && (!nccl_comm || !g_rccl.handle))
+        return fail(-1, "sfhip_step_group_create: neighbours on other ranks need a communicator and sfhip_rccl_bind");
+    G.comm = nccl_comm;
+    G.reduce_over_ranks = reduce_over_ranks;
+    G.side = (hipStream_t)side_stream;
+    hipError_t e = hipEventCreateWithFlags(&G.ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&G.joined, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(-1, hipGetErrorString(e));
+    for (int k = 0; k < npatches; ++k) g_plans[plans[k]].side = G.side;
+    G.used = 1;
+    g_groups[id] = G;
+    return id;
+}
+
+int sfhip_step_group_destroy(int group)
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    StepGroup *G = group_of(group);
+    if (!G) return -1;
+    (void)hipEventDestroy(G->ready);
+    (void)hipEventDestroy(G->joined);
+    *G = StepGroup();
+    return 0;
+}
+
+// sfhip_plan_step_rk2 for a group: `state` / `other` are HOST arrays of the patches' device pointers; everything
+// else, the outcomes 1 and 2 included, as there.  With reduce_over_ranks *slot_current must hold the maximum over
+// all ranks (as this call leaves *slot_next), so that every rank takes the same decisions.
+int sfhip_step_group_rk2(int group, double *const *state, double *const *other, double *slot_current, double *slot_next,
+                         double dx, double cfl, double time, const double *elements4, const double *shared4,
+                         double wavespeed_floor, double floor_fraction, double host_seq, double *result3)
+{
+    StepGroup *G = group_of(group);
+    if (!G) return -1;
+    if (!state || !other || !slot_current || !slot_next || !elements4 || !shared4 || !result3 || host_seq == 0.0)
+        return fail(-1, "sfhip_step_group_rk2: bad arguments");
+    using clock = std::chrono::steady_clock;
+    const auto c0 = clock::now();
+    double body[10], masses[18], next8[8];
+    if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], time, body))
+        return fail(-1, "sfhip_step_group_rk2: Kepler's equation did not converge");
+    pack_masses(body, shared4, masses);
+    int rc = group_stage(*G, state, nullptr, other, masses, nullptr, 0.0, NAN, 0, 0.0, nullptr, slot_current, dx, cfl,
+                         slot_next, host_seq);
+    if (rc) return rc;
+    const auto c1 = clock::now();
+    double amax = 0.0;
+    rc = sfhip_plan_host_wait(G->plans[0], host_seq, &amax);
+    if (rc) return step_failure(rc);
+    const auto c2 = clock::now();
+    result3[0] = amax;
+    if (amax < wavespeed_floor) return 1;
+    const double dt = dx / amax * cfl;                                  // driver.py:509-510
+    if (!(dt == dt)) return 2;
+    const double time0 = time;
+    const double t1 = time0 * 0.0 + (time + dt) * (1.0 - 0.0);          // cbdiso_2d.py:239 after stage 0
+    const double t2 = time0 * 0.5 + (t1 + dt) * (1.0 - 0.5);            // ... after stage 1
+    if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], t1, body))
+        return fail(-1, "sfhip_step_group_rk2: Kepler's equation did not converge");
+    pack_masses(body, shared4, masses);
+    if (kepler_orbital_state(elements4[0], elements4[1], elements4[2], elements4[3], t2, body))
+        return fail(-1, "sfhip_step_group_rk2: Kepler's equation did not converge");
+    for (int k = 0; k < 2; ++k) {
+        next8[4 * k + 0] = body[5 * k + 1]; next8[4 * k + 1] = body[5 * k + 2];
+        next8[4 * k + 2] = body[5 * k + 0]; next8[4 * k + 3] = shared4[0];
+    }
+    const auto c3 = clock::now();
+    // stage 1: other -> state in place over p^n; the new wavespeed accumulates in *slot_next (zeroed by stage 0)
+    rc = group_stage(*G, other, state, state, masses, next8, 0.5, dt, 1, floor_fraction * amax, slot_next, nullptr, 0.0, 0.0,
+                     nullptr, 0.0);
+    if (rc) return rc;
+    if (G->reduce_over_ranks) {
+        int st = g_rccl.AllReduce(slot_next, slot_next, 1, NCCL_UINT64, NCCL_MAX_OP, G->comm, G->compute);
+        if (st) return rccl_fail(st, "ncclAllReduce");
+    }
+    const auto c4 = clock::now();
+    G->phase_ns[0] += std::chrono::duration<double, std::nano>(c1 - c0).count();
+    G->phase_ns[1] += std::chrono::duration<double, std::nano>(c2 - c1).count();
+    G->phase_ns[2] += std::chrono::duration<double, std::nano>(c3 - c2).count();
+    G->phase_ns[3] += std::chrono::duration<double, std::nano>(c4 - c3).count();
+    G->steps_timed += 1;
+    result3[1] = dt;
+    result3[2] = t2;
+    return 0;
+}
+
+// as sfhip_plan_step_timing, for a group
+int sfhip_step_group_timing(int group, double *out5)
+{
+    StepGroup *G = group_of(group);
+    if (!G || !out5) return -1;
+    const double n = G->steps_timed > 0 ? (double)G->steps_timed : 1.0;
+    for (int k = 0; k < 4; ++k) { out5[k] = G->phase_ns[k] / n * 1e-3; G->phase_ns[k] = 0.0; }
+    out5[4] = (double)G->steps_timed;
+    G->steps_timed = 0;
     return 0;
 }
 

@@ -32,6 +32,16 @@ def _bind(module):
     module.sfhip_kepler_orbital_state.restype = i
     for name in ("create_cbdiso_2d", "create_cbdgam_2d", "set_side_stream", "destroy", "stage", "host_wait"):
         getattr(module, "sfhip_plan_" + name).restype = i
+    _c_int_p = ctypes.POINTER(ctypes.c_int)
+    module.sfhip_rccl_bind.argtypes = [ctypes.c_char_p]
+    module.sfhip_step_group_create.argtypes = [i, _c_int_p, _c_int_p, _c_int_p, _c_int_p, p, i, p]
+    module.sfhip_step_group_destroy.argtypes = [i]
+    module.sfhip_step_group_rk2.argtypes = [i, ctypes.POINTER(p), ctypes.POINTER(p), p, p, d, d, d, _c_double_p,
+                                            _c_double_p, d, d, d, _c_double_p]
+    module.sfhip_step_group_timing.argtypes = [i, _c_double_p]
+    for name in ("sfhip_rccl_bind", "sfhip_step_group_create", "sfhip_step_group_destroy", "sfhip_step_group_rk2",
+                 "sfhip_step_group_timing"):
+        getattr(module, name).restype = i
     module._sfhip_plan_bound = True
 
 
@@ -52,7 +62,7 @@ class StagePlan:
         self.lib = lib
         self.module = module = lib.module
         _bind(module)
-        stream = torch.cuda.current_stream().cuda_stream
+        self.stream = stream = torch.cuda.current_stream().cuda_stream
         create = module.sfhip_plan_create_cbdiso_2d if kind == "cbdiso_2d" else module.sfhip_plan_create_cbdgam_2d
         self.id = create(*patch.plan_constants(), ctypes.c_void_p(stream))
         if self.id < 0:
@@ -75,6 +85,16 @@ class StagePlan:
             self.close()
         except Exception:
             pass
+
+    def check_stream(self):
+        """A plan launches on the stream that was torch's current stream when it was made; the torch-side work of
+        a step (slot copies, all-reduces) follows torch's current stream.  They must be the same stream."""
+        import torch
+
+        now = torch.cuda.current_stream().cuda_stream
+        if now != self.stream:
+            raise self._error(f"launch plan made on stream {self.stream:#x}, but torch's current stream is {now:#x}: "
+                              "step the solver on the stream it was constructed on")
 
     def set_side_stream(self, stream):
         self.module.sfhip_plan_set_side_stream(self.id, ctypes.c_void_p(stream.cuda_stream))
@@ -134,3 +154,74 @@ class StagePlan:
             raise self._error(f"sfhip_plan_host_wait failed: {self.lib.last_error()}")
         return self._host_value.value
 
+
+
+PEER_EDGE, PEER_LOCAL = -1, -2  # neighbour codes of sfhip_step_group_create (a rank number otherwise)
+
+
+class StepGroup:
+    """
+    All the patches a process owns, stepped from one C call (include/sfhip.h, "step groups"): per stage the slab
+    copies between the group's patches, the interior launches, one RCCL group of sends and receives on the side
+    stream, the rows behind the halos, and after the last stage the MAX all-reduce of the wavespeed slot.
+
+    `patches`: in global patch order, each with a StagePlan; `global_ids`: their patch numbers; `lower` / `upper`:
+    per patch PEER_EDGE, PEER_LOCAL or the rank that owns the neighbour; `rccl`: an RcclComm (kernel/rccl.py) when
+    any neighbour is on another rank or the slot is to be reduced over ranks.
+    """
+
+    def __init__(self, lib, patches, global_ids, lower, upper, rccl, reduce_over_ranks, side_stream, elements4, shared4):
+        from .library import KernelError
+
+        self._error = KernelError
+        self.lib = lib
+        self.module = module = lib.module
+        _bind(module)
+        n = len(patches)
+        if rccl is not None and module.sfhip_rccl_bind(rccl.library_path.encode()) != 0:
+            raise KernelError(f"sfhip_rccl_bind failed: {lib.last_error()}")
+        ints = ctypes.c_int * n
+        self.id = module.sfhip_step_group_create(
+            n, ints(*[p.plan.id for p in patches]), ints(*global_ids), ints(*lower), ints(*upper),
+            rccl.comm if rccl is not None else None, 1 if reduce_over_ranks else 0,
+            ctypes.c_void_p(side_stream.cuda_stream) if side_stream is not None else None)
+        if self.id < 0:
+            raise KernelError(f"sfhip_step_group_create failed: {lib.last_error()}")
+        self._keep = (rccl, side_stream)
+        self._n = n
+        self._state = (ctypes.c_void_p * n)()
+        self._other = (ctypes.c_void_p * n)()
+        self._elements = (ctypes.c_double * 4)(*elements4)
+        self._shared = (ctypes.c_double * 4)(*shared4)
+        self._result = (ctypes.c_double * 3)()
+        self._step = module.sfhip_step_group_rk2
+
+    def close(self):
+        if self.id >= 0:
+            self.module.sfhip_step_group_destroy(self.id)
+            self.id = -1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step_rk2(self, states, others, slot_current, slot_next, dx, cfl, time, wavespeed_floor, floor_fraction, host_seq):
+        """One RK2 step of every patch (sfhip_step_group_rk2).  Returns (redo, amax, dt, time_after)."""
+        for k in range(self._n):
+            self._state[k] = states[k].data_ptr()
+            self._other[k] = others[k].data_ptr()
+        status = self._step(self.id, self._state, self._other, slot_current.data_ptr(), slot_next.data_ptr(), dx, cfl, time,
+                            self._elements, self._shared, wavespeed_floor, floor_fraction, host_seq, self._result)
+        if status not in (0, 1, 2):
+            raise self._error(f"sfhip_step_group_rk2 failed ({status}): {self.lib.last_error()}")
+        r = self._result
+        if status == 2:
+            return False, r[0], float("nan"), float("nan")
+        return status == 1, r[0], r[1], r[2]
+
+    def step_timing(self):
+        out = (ctypes.c_double * 5)()
+        self.module.sfhip_step_group_timing(self.id, out)
+        return tuple(out)

@@ -10,16 +10,23 @@ kernels of well under 0.1 ms on the slabs of a strong-scaling run.  The same fou
 host, and completion is an event on the stream.
 
 The communicator is created collectively (``RcclComm.create``): rank 0 makes the unique id, it travels to the
-other ranks through the existing torch.distributed group, every rank calls ``ncclCommInitRank``.  Opt-in
-(``SFHIP_HALO_TRANSPORT=rccl`` or ``Solver(..., halo_transport="rccl")``): on the one-GPU development box only
-a one-rank communicator can run (tests/test_distributed_gpu.py), so the torch.distributed transport, which
-the multi-rank CPU tests cover end to end, stays the default.
+other ranks through the existing torch.distributed group, every rank calls ``ncclCommInitRank``.  It is the
+default transport of device runs whose torch.distributed backend is RCCL (``SFHIP_HALO_TRANSPORT=torch`` selects
+torch.distributed's own calls instead); if any rank fails to join, every rank falls back to torch.distributed
+together (``SolverBase._create_rccl``).  The same communicator is handed to libsfhip.so's step groups
+(``sfhip_step_group_*``), which then issue these calls from C (``library_path`` names the file to bind).
+
+The MAX all-reduce of the wavespeed slot reduces the doubles' BIT PATTERNS as ``ncclUint64``: for non-negative
+doubles the patterns order like the values, and a NaN's pattern ranks above every finite value and infinity, so
+a rank whose state has blown up gives every rank a NaN dt -- as the one-rank fold (``max_nan``, the integer
+``atomicMax``) does.  ``ncclMax`` on ``ncclDouble`` is free to drop the NaN.
 """
 import ctypes
 import os
 
 NCCL_UNIQUE_ID_BYTES = 128
 NCCL_FLOAT64 = 8   # ncclDataType_t: ncclDouble
+NCCL_UINT64 = 5    # ncclDataType_t: ncclUint64
 NCCL_MAX = 2       # ncclRedOp_t
 
 
@@ -61,9 +68,12 @@ def _load():
     lib.ncclAllReduce.argtypes = [vp, vp, sz, i, i, vp, vp]
     lib.ncclGetErrorString.argtypes = [i]
     lib.ncclGetErrorString.restype = ctypes.c_char_p
+    lib.ncclCommCount.argtypes = [vp, ctypes.POINTER(i)]
+    lib.ncclCommUserRank.argtypes = [vp, ctypes.POINTER(i)]
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd",
-                 "ncclSend", "ncclRecv", "ncclAllReduce"):
+                 "ncclSend", "ncclRecv", "ncclAllReduce", "ncclCommCount", "ncclCommUserRank"):
         getattr(lib, name).restype = i
+    lib.sfhip_path = path  # the file this handle came from: libsfhip.so binds the same one (sfhip_rccl_bind)
     return lib
 
 
@@ -107,10 +117,22 @@ class RcclComm:
                         "ncclSend" if kind == "send" else "ncclRecv")
         self._check(lib, lib.ncclGroupEnd(), "ncclGroupEnd")
 
+    @property
+    def library_path(self):
+        return self.lib.sfhip_path
+
+    def count(self):
+        """Number of ranks as RCCL itself reports it (ncclCommCount) and this process's rank in it."""
+        n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._check(self.lib, self.lib.ncclCommCount(self.comm, ctypes.byref(n)), "ncclCommCount")
+        self._check(self.lib, self.lib.ncclCommUserRank(self.comm, ctypes.byref(r)), "ncclCommUserRank")
+        return n.value, r.value
+
     def max_scalar(self, tensor, stream):
-        """In-place MAX all-reduce of a float64 device tensor on `stream`."""
+        """In-place MAX all-reduce on `stream` of a float64 device tensor of NON-NEGATIVE values (or NaN), exact and
+        NaN-keeping: reduced as the unsigned integers their bit patterns are (see the module docstring)."""
         ptr = tensor.data_ptr()
-        self._check(self.lib, self.lib.ncclAllReduce(ptr, ptr, tensor.numel(), NCCL_FLOAT64, NCCL_MAX, self.comm, stream),
+        self._check(self.lib, self.lib.ncclAllReduce(ptr, ptr, tensor.numel(), NCCL_UINT64, NCCL_MAX, self.comm, stream),
                     "ncclAllReduce")
 
     def close(self):

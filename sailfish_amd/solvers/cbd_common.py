@@ -124,15 +124,28 @@ class Comm:
         return self._staged
 
     def max_scalar(self, tensor):
-        """In-place MAX all-reduce of a one-element tensor (order independent: bit-exact)."""
+        """
+        In-place MAX all-reduce of a one-element float64 tensor of NON-NEGATIVE values (wavespeeds), exact and
+        NaN-keeping.  A backend's floating-point MAX is free to drop a NaN (fmax semantics, or whatever the argument
+        order gives), and then a rank whose state has blown up would not stop the others: the reference, and the
+        one-rank fold here (max_nan, the integer atomicMax), hand every caller a NaN dt.  So the BIT PATTERNS are
+        reduced, as integers: for non-negative doubles they order like the values, and a NaN's pattern (sign bit
+        cleared) ranks above every finite value and infinity.
+        """
         if self.enabled:
             if self.host_staged and getattr(tensor, "is_cuda", False):
                 host = tensor.cpu()  # waits for the current stream: the value is final
-                self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX)
+                self._max_of_bit_patterns(host)
                 tensor.copy_(host)
             else:
-                self.dist.all_reduce(tensor, op=self.dist.ReduceOp.MAX)
+                self._max_of_bit_patterns(tensor)
         return tensor
+
+    def _max_of_bit_patterns(self, tensor):
+        import torch
+
+        tensor.abs_()  # a sign-bit operation: x86 makes NaNs with the sign bit set, which would rank lowest as int64
+        self.dist.all_reduce(tensor.view(torch.int64), op=self.dist.ReduceOp.MAX)
 
     def host_group(self):
         """
@@ -313,7 +326,9 @@ class SolverBase:
     default_rk_order = 2
     _staging = None   # pinned host buffers of the exchange over a gloo group (_start_host_staged_exchange)
     wavespeed_redos = 0   # steps whose stage 0 was repeated because the filtered wavespeed fell below its floor
-    _rccl = None      # direct RCCL transport (kernel/rccl.py): only solvers set up by _setup_patches may opt in
+    _rccl = None      # direct RCCL transport (kernel/rccl.py): solvers set up by _setup_patches
+    _self_exchange = False
+    _group = None
 
     def _setup_patches(self, setup, mesh, time, solution, num_patches, mode, backend, fused, distributed,
                        initial_condition):
@@ -349,7 +364,7 @@ class SolverBase:
         self.num_patches = num_patches
         self.patch_ranges = ranges
         self.local_ids = list(range(self.comm.rank * per_rank, (self.comm.rank + 1) * per_rank))
-        self.owner = lambda k: k // per_rank
+        self.owner = lambda k: k // per_rank  # (one rank: 0, which is also what a self-exchange sends to)
 
         logger.info(f"initiate with time={time:0.4f}")
         logger.info(f"subdivide grid over {num_patches} patches on {world} rank(s)")
@@ -388,27 +403,51 @@ class SolverBase:
             self.patches.append(patch)
         self._comm_stream = None
         self._rccl = None
-        # "torch" (default): halo slabs and the wavespeed all-reduce through torch.distributed; "rccl": through RCCL
-        # called directly on the solver's streams (kernel/rccl.py)
-        self.halo_transport = os.environ.get("SFHIP_HALO_TRANSPORT", "torch")
+        # Halo slabs and the wavespeed all-reduce between ranks: "rccl" = RCCL called directly on the solver's
+        # streams (kernel/rccl.py; from C inside a step group), the default where the torch.distributed backend is
+        # RCCL; "torch" = torch.distributed's own calls (always over a gloo group).  If any rank cannot join the
+        # direct communicator, all ranks fall back to "torch" together (_create_rccl).
+        # SFHIP_SELF_EXCHANGE=1 (tests; no torch.distributed): the halos between the patches of ONE process travel
+        # through a one-rank RCCL communicator, sends and receives to the own rank -- all of the multi-rank data
+        # path that a one-GPU box can run.
+        self._self_exchange = bool(os.environ.get("SFHIP_SELF_EXCHANGE")) and not self.comm.enabled and backend.mode == "hip"
+        default_transport = "rccl" if (self.comm.enabled and backend.mode == "hip"
+                                       and self.comm.dist.get_backend() == "nccl") else "torch"
+        self.halo_transport = os.environ.get("SFHIP_HALO_TRANSPORT", default_transport)
         if self.comm.enabled and backend.mode == "hip" and self.halo_transport == "rccl":
             self._rccl = self._create_rccl()
+            if self._rccl is None:
+                self.halo_transport = "torch"
+        elif self._self_exchange:
+            from ..kernel.rccl import RcclComm
+
+            with self.patches[0].execution_context:
+                self._rccl = RcclComm.create(None, 0, 1)
+            self.halo_transport = "rccl"
         if backend.mode == "hip" and fused and not os.environ.get("SFHIP_NO_PLANS"):
             from ..kernel.plan import StagePlan
 
             for p in self.patches:
                 with p.execution_context:
                     p.plan = StagePlan(p.lib, p, type(self).__module__.rsplit(".", 1)[-1])
-        # A whole RK2 step from one C call (sfhip_plan_step_rk2) where nothing needs Python between the stages:
-        # one patch, no other ranks, and point masses that are the setup's own Kepler binary.
+        # A whole RK2 step from one C call where nothing needs Python between the stages: point masses that are
+        # the setup's own Kepler binary, every patch on one device, and either no other ranks or the direct RCCL
+        # transport.  One patch without neighbours: sfhip_plan_step_rk2; otherwise a step group
+        # (sfhip_step_group_rk2: slab copies / RCCL exchange, interior and boundary launches, all-reduce).
         self._c_step = False
+        self._group = None
         fn = getattr(self._physics, "point_mass_function", None)
-        if (len(self.patches) == 1 and not self.comm.enabled and self.patches[0].plan is not None
-                and hasattr(setup, "kepler_binary") and getattr(fn, "__self__", None) is setup
-                and getattr(fn, "__func__", None) is getattr(type(setup), "point_masses", None)
-                and not os.environ.get("SFHIP_NO_C_STEP")):
-            self.patches[0].plan.set_kepler_binary(*setup.kepler_binary())
-            self._c_step = True
+        kepler = (hasattr(setup, "kepler_binary") and getattr(fn, "__self__", None) is setup
+                  and getattr(fn, "__func__", None) is getattr(type(setup), "point_masses", None))
+        plans = bool(self.patches) and all(p.plan is not None for p in self.patches)
+        if plans and kepler and not os.environ.get("SFHIP_NO_C_STEP"):
+            if len(self.patches) == 1 and not self.comm.enabled:
+                self.patches[0].plan.set_kepler_binary(*setup.kepler_binary())
+                self._c_step = True
+            elif (len({str(p.primitive1.device) for p in self.patches}) == 1
+                  and (self._rccl is not None or not self.comm.enabled)
+                  and all(p.shape[0] >= 2 * NG for p in self.patches)):
+                self._group = self._create_step_group(setup)
         self._mass_cache = (None, None)
         self._wavespeed_floor = 0.0
         self._dt_dev = None
@@ -424,6 +463,34 @@ class SolverBase:
 
     def _patch_kwargs(self):
         return {}
+
+    def _create_step_group(self, setup):
+        """The C-side step group of this process's patches (kernel/plan.py: StepGroup)."""
+        from ..kernel.plan import PEER_EDGE, PEER_LOCAL, StepGroup
+
+        local = set(self.local_ids)
+        lower, upper = [], []
+        for k in self.local_ids:
+            codes = []
+            for n in self._neighbors(k):
+                if n is None:
+                    codes.append(PEER_EDGE)
+                elif n in local and not self._self_exchange:
+                    codes.append(PEER_LOCAL)
+                else:
+                    codes.append(self.owner(n))
+            lower.append(codes[0])
+            upper.append(codes[1])
+        remote = any(c >= 0 for c in lower + upper)
+        torch = self._torch()
+        with self.patches[0].execution_context:
+            if remote and self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+                for p in self.patches:
+                    p.plan.set_side_stream(self._comm_stream)
+            return StepGroup(self.patches[0].lib, self.patches, self.local_ids, lower, upper,
+                             self._rccl if (remote or self.comm.enabled) else None, self.comm.enabled,
+                             self._comm_stream if remote else None, *setup.kepler_binary())
 
     def _create_rccl(self):
         """Collective: every rank tries to join a direct RCCL communicator; all fall back together if any failed."""
@@ -694,7 +761,7 @@ class SolverBase:
 
     def _has_remote_neighbors(self):
         if self._remote_neighbors is None:
-            local = set(self.local_ids)
+            local = set() if self._self_exchange else set(self.local_ids)
             self._remote_neighbors = any(
                 n is not None and n not in local for k in self.local_ids for n in self._neighbors(k))
         return self._remote_neighbors
@@ -735,12 +802,21 @@ class SolverBase:
                 with p0.execution_context:
                     cur.copy_(amax_dev)
             plan = getattr(p0, "plan", None)
-            if self._c_step and self.event_log is None and params == [0.0, 0.5]:
-                # everything between here and the end of the step in one C call (include/sfhip.h)
+            if (self._c_step or self._group is not None) and self.event_log is None and params == [0.0, 0.5]:
+                # everything between here and the end of the step in one C call (include/sfhip.h): one patch
+                # without neighbours through its plan, several patches and / or other ranks through the step group
                 self._host_seq += 1.0
-                redo, amax, dt, t_after = plan.step_rk2(
-                    p0.primitive1, p0.primitive2, cur, nxt, float(dx), float(cfl_number), p0.time,
-                    floor if filtered else 0.0, WAVESPEED_FLOOR_FRACTION, self._host_seq)
+                if self._host_seq % 256.0 == 1.0:
+                    plan.check_stream()  # the plans launch on the stream they were made on
+                if self._c_step:
+                    redo, amax, dt, t_after = plan.step_rk2(
+                        p0.primitive1, p0.primitive2, cur, nxt, float(dx), float(cfl_number), p0.time,
+                        floor if filtered else 0.0, WAVESPEED_FLOOR_FRACTION, self._host_seq)
+                else:
+                    redo, amax, dt, t_after = self._group.step_rk2(
+                        [p.primitive1 for p in self.patches], [p.primitive2 for p in self.patches], cur, nxt,
+                        float(dx), float(cfl_number), p0.time, floor if filtered else 0.0, WAVESPEED_FLOOR_FRACTION,
+                        self._host_seq)
                 if redo:
                     filtered = False
                     self._slot_valid = False
@@ -751,12 +827,13 @@ class SolverBase:
                     # do, in the Kepler solve of the next stage time (kepler.py:356-366: floor of a NaN)
                     self.point_masses(p0.stage_time(0.0, dt))
                 self._wavespeed_floor = WAVESPEED_FLOOR_FRACTION * amax
-                p0.time0 = p0.time
-                p0.time = p0.stage_time(0.0, dt)
-                p0.time = p0.stage_time(0.5, dt)  # (the buffers swap twice: the state is where it was)
+                for p in self.patches:
+                    p.time0 = p.time
+                    p.time = p.stage_time(0.0, dt)
+                    p.time = p.stage_time(0.5, dt)  # (the buffers swap twice: the state is where it was)
+                    p.wavespeed_valid = False
                 if p0.time != t_after and not (p0.time != p0.time and t_after != t_after):  # (a NaN dt gives NaN twice)
-                    raise RuntimeError(f"sfhip_plan_step_rk2 and Patch.stage_time disagree: {t_after!r} != {p0.time!r}")
-                p0.wavespeed_valid = False
+                    raise RuntimeError(f"the C step and Patch.stage_time disagree: {t_after!r} != {p0.time!r}")
                 self._slot_cur = 1 - self._slot_cur
                 self._slot_valid = True
                 return dt
@@ -877,10 +954,11 @@ class SolverBase:
         that event only, so what `between` queues on the compute stream (the interior launch) does not
         hold the exchange back and is not held back by the host time of the transport calls.
         """
-        local = {k: p for k, p in zip(self.local_ids, self.patches)}
+        mine = {k: p for k, p in zip(self.local_ids, self.patches)}
+        local = {} if self._self_exchange else mine  # (a self-exchange sends every slab through RCCL, to the own rank)
         ng = self.num_guard
         ops = []
-        for k, p in local.items():
+        for k, p in mine.items():
             lower, upper = self._neighbors(k)
             pc = getattr(p, array)
             if lower is not None and lower in local:

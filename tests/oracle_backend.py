@@ -80,7 +80,8 @@ class OracleLibrary:
     def _fold(self, out_t, value, want):
         if want == 2:
             out_t.zero_()
-        out_t[0] = max(float(out_t[0]), value)
+        cur = float(out_t[0])
+        out_t[0] = value if (value > cur or value != value) else cur  # max_nan of the kernels: a NaN survives the fold
 
     def reductions_workspace_len(self, ni, nj):
         return 16

@@ -250,3 +250,61 @@ def test_reductions_over_ranks():
         assert p.exitcode == 0
     for rank, ok, err in results:
         assert ok, (rank, err)
+
+
+def _nan_worker(rank, world, port, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_backend import OracleBackend
+        from sailfish_amd.setups import make_setup
+        from sailfish_amd.solvers import make_solver
+        from sailfish_amd.solvers.cbd_common import Comm
+
+        comm = Comm(True)
+        ok = True
+        # the reduction itself: finite values give the exact maximum; one NaN, of either sign bit, wins on every rank
+        t = torch.tensor([0.25 + rank], dtype=torch.float64)
+        ok &= float(comm.max_scalar(t)) == 0.25 + (world - 1)
+        for nan in (float("nan"), -float("nan"), float(np.float64(0.0) * np.float64("inf"))):
+            t = torch.tensor([nan if rank == 1 else 3.0 + rank], dtype=torch.float64)
+            ok &= bool(torch.isnan(comm.max_scalar(t)).item())
+        t = torch.tensor([float("inf") if rank == 0 else 1.0], dtype=torch.float64)
+        ok &= float(comm.max_scalar(t)) == float("inf")
+        # a solver whose rank 1 holds a NaN zone: every rank's maximum_wavespeed() is NaN (as numpy's max over the
+        # reference's wavespeed array is), so dt is NaN everywhere and no rank carries on with a finite one
+        setup = make_setup("circumbinary-disk")
+        mesh = setup.mesh(32)
+        s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=world,
+                        backend=OracleBackend())
+        if rank == 1:
+            s.patches[0].primitive1[5, 7, 2] = float("nan")
+        amax = s.maximum_wavespeed()
+        ok &= amax != amax
+        queue.put((rank, bool(ok), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nan_wavespeed_reaches_every_rank():
+    """The MAX all-reduce of the wavespeed keeps a NaN (reduced on the bit patterns): a blown-up rank stops all."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    results = [queue.get(timeout=5) for _ in range(world)]
+    for p in procs:
+        assert p.exitcode == 0
+    for rank, ok, err in results:
+        assert ok, (rank, err)

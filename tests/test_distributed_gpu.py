@@ -167,12 +167,14 @@ def _nccl_single_rank_worker(port, queue):
         mesh = setup.mesh(96)
         physics = dict(setup.physics, diagnostics=[Diagnostic("mass"), Diagnostic("mdot", accretion=True, which_mass=1)])
         kw = dict(setup=setup, mesh=mesh, time=0.0, num_patches=2, mode="hip")
-        a = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # every collective goes through RCCL / gloo
         b = make_solver(setup.solver, physics, {}, distributed=False, **kw)
-        os.environ["SFHIP_HALO_TRANSPORT"] = "rccl"
-        c = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # ... through RCCL called directly
+        os.environ["SFHIP_HALO_TRANSPORT"] = "torch"
+        a = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # every collective through torch.distributed
         del os.environ["SFHIP_HALO_TRANSPORT"]
+        c = make_solver(setup.solver, physics, {}, distributed=True, **kw)   # default on RCCL: called directly, from C
         assert a.comm.enabled and a.comm.size == 1 and not b.comm.enabled and a._rccl is None and c._rccl is not None
+        assert c._group is not None and a._group is None and b._group is not None
+        assert c._rccl.count() == (1, 0)                                        # ncclCommCount / ncclCommUserRank
         dts_a = [a.step(0.3) for _ in range(4)]
         dts_b = [b.step(0.3) for _ in range(4)]
         dts_c = [c.step(0.3) for _ in range(4)]
@@ -188,6 +190,16 @@ def _nccl_single_rank_worker(port, queue):
                          side.cuda_stream)
         side.synchronize()
         same = same and bool(torch.equal(x, y))
+        # a blown-up rank must give every rank a NaN: both MAX all-reduces keep it, whatever its sign bit
+        for nan in (float("nan"), -float("nan")):
+            t = torch.tensor([nan], dtype=torch.float64, device="cuda")
+            c._rccl.max_scalar(t, torch.cuda.current_stream().cuda_stream)
+            same = same and bool(torch.isnan(t).item())
+            t = torch.tensor([nan], dtype=torch.float64, device="cuda")
+            same = same and bool(torch.isnan(a.comm.max_scalar(t)).item())
+        t = torch.tensor([2.5], dtype=torch.float64, device="cuda")
+        c._rccl.max_scalar(t, torch.cuda.current_stream().cuda_stream)
+        same = same and float(a.comm.max_scalar(t).item()) == 2.5
         same = same and bool(np.array_equal(a.solution, b.solution))            # gather over the gloo side group
         same = same and a.reductions() == b.reductions()                        # per-patch sums all-gathered
         same = same and a.comm.host_group() is not None                         # RCCL is the default group, gloo beside it
@@ -198,9 +210,79 @@ def _nccl_single_rank_worker(port, queue):
 
 def test_rccl_process_group_single_rank():
     """What can run of the RCCL path on one GPU: a one-rank `nccl` process group under the solver -- the MAX
-    all-reduce of the device-side wavespeed slot on RCCL, the gloo side group for host gathers created beside
-    it, rank-0 gather and all-gather of diagnostics -- equal to the run without torch.distributed, bit for bit.
-    (Halo slabs between ranks need two devices; their posting order is what the gloo tests cover.)"""
+    all-reduce of the device-side wavespeed slot on RCCL (through torch.distributed, and directly from the C
+    step group, which is the default), NaN-keeping; the gloo side group for host gathers created beside it,
+    rank-0 gather and all-gather of diagnostics -- equal to the run without torch.distributed, bit for bit.
+    (Halo slabs through RCCL: test_step_group_self_exchange.)"""
     port = _free_port()
     for rank, err, _ in _run_ranks(_nccl_single_rank_worker, lambda r: (port,), world=1):
         assert err == 0.0
+
+
+def _step_group_worker(kind, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    from sailfish_amd.setups import make_setup
+    from sailfish_amd.solvers import make_solver
+
+    setup = make_setup("circumbinary-disk", eos="isothermal" if kind == "iso" else "gamma-law")
+    mesh = setup.mesh(128)
+    cfl = 0.3 if kind == "iso" else 0.1
+
+    def build(num_patches, **env):
+        os.environ.update(env)
+        try:
+            return make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0,
+                               num_patches=num_patches, mode="hip", distributed=False)
+        finally:
+            for k in env:
+                del os.environ[k]
+
+    solvers = dict(
+        one_patch=build(1),                                                    # sfhip_plan_step_rk2
+        python_copies=build(4, SFHIP_NO_C_STEP="1"),                           # Python stages, device slab copies
+        group_copies=build(4),                                                 # step group, device slab copies
+        python_rccl=build(4, SFHIP_NO_C_STEP="1", SFHIP_SELF_EXCHANGE="1"),    # Python stages, RCCL to the own rank
+        group_rccl=build(4, SFHIP_SELF_EXCHANGE="1"),                          # step group, RCCL to the own rank
+        group_rccl_5=build(5, SFHIP_SELF_EXCHANGE="1"),                        # ragged slabs (26, 26, 26, 25, 25 rows)
+    )
+    g = solvers
+    ok = g["one_patch"]._c_step and g["one_patch"]._group is None
+    ok = ok and g["python_copies"]._group is None and g["python_rccl"]._group is None
+    ok = ok and g["group_copies"]._group is not None and g["group_copies"]._rccl is None
+    ok = ok and g["group_rccl"]._group is not None and g["group_rccl"]._rccl is not None and g["python_rccl"]._rccl is not None
+    dts = {name: [s.step(cfl) for _ in range(6)] for name, s in solvers.items()}
+    final = {name: s.solution for name, s in solvers.items()}
+    amax = {name: s.maximum_wavespeed() for name, s in solvers.items()}
+    worst = 0.0
+    for name in solvers:
+        if name == "group_rccl_5":
+            # 128 rows in 5 slabs: dx = (xr - xl) / ni differs in the last place between patches (SURVEY section 4
+            # item 5), so this one is held to the tolerance, not to the bits
+            err = np.abs(final[name] - final["one_patch"]).max(axis=-1) / np.maximum(np.abs(final["one_patch"]).max(axis=-1), 1e-300)
+            worst = float(err.max())
+            ok = ok and worst <= 1e-12 and all(abs(a - b) <= 1e-13 * b for a, b in zip(dts[name], dts["one_patch"]))
+        else:
+            ok = ok and dts[name] == dts["one_patch"] and amax[name] == amax["one_patch"]
+            ok = ok and bool(np.array_equal(final[name], final["one_patch"]))
+    ok = ok and solvers["group_rccl"].time == solvers["one_patch"].time
+    # host time of the C step with the exchange active (tools/hostprof.py prints the same for a 512 x 4096 slab)
+    timing = solvers["group_rccl"]._group.step_timing()
+    queue.put((0, 0.0 if ok else float("inf"), worst, timing))
+
+
+@pytest.mark.parametrize("kind", ["iso", "gam"])
+def test_step_group_self_exchange(kind):
+    """
+    The multi-rank step from C (sfhip_step_group_rk2) on what one GPU can run of it: four slab patches in one
+    process whose halo slabs travel through a one-rank RCCL communicator as grouped ncclSend / ncclRecv to the own
+    rank on the side stream, rows behind the halos launched there, interiors on the compute stream.  Bit for bit
+    equal to the same exchange driven from Python, to device-to-device slab copies (from C and from Python) and
+    to the one-patch run: same dt sequence, same final state, same reduced wavespeed.
+    """
+    for _, err, worst, timing in _run_ranks(_step_group_worker, lambda r: (kind,), world=1):
+        assert err == 0.0, (worst, timing)
