@@ -18,8 +18,13 @@ Workloads
   N > 1   headline (``value``): WEAK scaling at 4096^2 zones per GPU -- a square mesh of 4096*sqrt(N) per side
           cut into N slab patches, one per rank, halo slabs and the dt MAX all-reduce on RCCL.
           Also measured in the same run and reported beside it (never as ``value``):
-            "strong_scaling"  BASELINE.json's metric line, the 4096^2 mesh cut into N slabs;
-            "config2"         at N = 8: BASELINE.json configs[2], 16384^2 (2048 x 16384 per rank).
+            "metric_config"   BASELINE.json's metric line, the 4096^2 mesh cut into N slabs (strong scaling; the
+                              same object is also printed as "strong_scaling");
+            "config2"         at N = 8: BASELINE.json configs[2], cbdiso_2d 16384^2 (2048 x 16384 per rank);
+            "config3"         at N = 8: BASELINE.json configs[3], cbdgam_2d 8192^2 (1024 x 8192 per rank).
+          "ranks" proves what ran: the number of ranks RCCL itself reports for the communicator the halos and the
+          all-reduce travel on (ncclCommCount), every rank's device (PCI bus id, UUID), the transport and whether
+          the one-call step group stepped the patches.
 Initial data are the setup's analytic disk (no RNG, no files), resident in HBM before the clock starts.
 
 Output fields beyond the driver's contract
@@ -30,6 +35,9 @@ Output fields beyond the driver's contract
                  each); the committed profiles/traffic.json when such a pass is not possible, with the reason
   roofline_valu  what actually binds: the kernel's fp64 VALU instruction stream (count per launch and the clock
                  under the kernel from two more such passes) against the issue rate of 1024 SIMDs
+  cold_ms_per_step  the first K steps of a fresh solver after ONE untimed step (code-object load, exact wavespeed
+                 pass), with the device's clocks still at idle: what the reference's own per-fold Mzps printout
+                 (driver.py:514-517) shows for its first folds.  `ms_per_step` / `value` are the ramped figures.
   cpu_baseline   the reference's own C/OpenMP kernels (oracle/_ref, built from /root/reference by
                  oracle/build_ref.py) or, where absent, our C port (oracle/sf_oracle.c), driven in the
                  reference's order on a bounded sample of the same workload (N = 1, rank 0 only).
@@ -91,8 +99,9 @@ def parse_args():
                     help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic and roofline_valu (N = 1)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: measure the headline workload only")
     ap.add_argument("--halo-transport", default=None, choices=["torch", "rccl"],
-                    help="N > 1: halo slabs and the wavespeed all-reduce through torch.distributed (default) or through "
-                         "RCCL called directly on the solver's streams (sailfish_amd/kernel/rccl.py)")
+                    help="N > 1: halo slabs and the wavespeed all-reduce through RCCL called directly, from C inside the "
+                         "one-call step (default on an RCCL process group; sailfish_amd/kernel/rccl.py), or through "
+                         "torch.distributed's own calls")
     ap.add_argument("--ramp-seconds", type=float, default=0.5,
                     help="untimed steps of the same workload run for this long BEFORE the W warmup steps, so that "
                          "the GPU's clocks have left their idle state when the (short) timed region starts; the "
@@ -344,7 +353,27 @@ def bracket_overhead_ms(torch, samples=40):
     return times[len(times) // 2]
 
 
-def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
+def transport_proof(ranks, solver):
+    """What carried the halos and the dt all-reduce of this solver, as the libraries themselves report it."""
+    torch = ranks.torch
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    mine = dict(rank=ranks.rank, device=torch.cuda.current_device(),
+                pci="%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                        getattr(props, "pci_device_id", 0)),
+                uuid=str(getattr(props, "uuid", "")), name=props.name)
+    rccl = getattr(solver, "_rccl", None)
+    if rccl is not None:
+        mine["rccl_comm_count"], mine["rccl_comm_rank"] = rccl.count()  # ncclCommCount / ncclCommUserRank
+    mine["halo_transport"] = getattr(solver, "halo_transport", None)
+    mine["step_group"] = getattr(solver, "_group", None) is not None
+    if ranks.dist is None:
+        return [mine]
+    everyone = [None] * ranks.world
+    ranks.dist.all_gather_object(everyone, mine)
+    return everyone
+
+
+def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events, measure_cold=False):
     """Build the workload, run `warmup` untimed and `steps` timed steps between fences; MAX seconds over ranks."""
     torch = ranks.torch
     from sailfish_amd.driver import timestep
@@ -374,6 +403,18 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
         else:
             solver.step(cfl)  # same dt and same work; no host round trip on the critical path
 
+    proof = transport_proof(ranks, solver)
+    # Cold figure: one untimed step (lazy code-object load, the exact wavespeed pass of a new solver), then the
+    # same K steps between the same fences, before any clock ramp.
+    cold_ms = None
+    if measure_cold:
+        step()
+        ranks.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ranks.fence()
+        cold_ms = ranks.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
     ramp_steps = 0
     if args.ramp_seconds > 0.0:
         # The device leaves its idle clocks only after some tens of milliseconds of load: with the round driver's
@@ -413,7 +454,8 @@ def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events):
     result = dict(resolution=resolution, setup=setup, setup_name=setup_name, setup_kwargs=setup_kwargs, mesh=mesh, seconds=seconds,
                   steps=steps, zones=mesh.num_total_zones, mzps=mesh.num_total_zones * steps / seconds * 1e-6,
                   ms_per_step=seconds / steps * 1e3, event_log=event_log, stride=stride, ramp_steps=ramp_steps,
-                  patch_shape=tuple(solver.patches[0].shape), redos=getattr(solver, "wavespeed_redos", 0) - redos_before)
+                  patch_shape=tuple(solver.patches[0].shape), redos=getattr(solver, "wavespeed_redos", 0) - redos_before,
+                  cold_ms_per_step=cold_ms, proof=proof)
     if use_events and event_log:
         result["bracket_overhead_ms"] = bracket_overhead_ms(torch)
     del solver
@@ -498,11 +540,29 @@ def roofline_of(args, run, world):
 
 
 def summary(run, world, bytes_per_update):
+    proof = run.get("proof") or []
     return dict(
+        halo_transport=proof[0].get("halo_transport") if proof else None,
+        step_group=all(r.get("step_group") for r in proof) if proof else None,
         workload=f"{run['setup'].solver} {run['setup_name']} {run['mesh'].shape[0]}x{run['mesh'].shape[1]} fp64, RK2, "
                  f"{world} slab patch(es) of {run['patch_shape'][0]}x{run['patch_shape'][1]}, one per GPU",
         value=round(run["mzps"], 2), unit="Mzps", ms_per_step=round(run["ms_per_step"], 4), steps=run["steps"],
         hbm_roofline_frac_whole_step=round(run["mzps"] * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
+    )
+
+
+def ranks_object(proof, world, transport):
+    """The N ranks as the libraries report them: distinct devices, and RCCL's own count of the communicator."""
+    counts = sorted({r.get("rccl_comm_count") for r in proof if r.get("rccl_comm_count") is not None})
+    return dict(
+        world_size=world,
+        rccl_comm_count=counts[0] if len(counts) == 1 else (counts or None),  # ncclCommCount on every rank
+        rccl_comm_ranks=sorted(r["rccl_comm_rank"] for r in proof if "rccl_comm_rank" in r) or None,
+        distinct_devices=len({(r["pci"], r["uuid"]) for r in proof}),
+        devices=[dict(rank=r["rank"], pci=r["pci"], uuid=r["uuid"], name=r["name"]) for r in proof],
+        halo_transport=sorted({str(r.get("halo_transport")) for r in proof}),
+        step_group=all(r.get("step_group") for r in proof),
+        process_group="gloo (rehearsal: every rank on cuda:0)" if transport == "gloo" else ("RCCL" if world > 1 else None),
     )
 
 
@@ -537,7 +597,8 @@ def main():
     else:
         counters_now = {"traffic": (None, "N > 1" if world > 1 else None), "valu": (None, "N > 1" if world > 1 else None)}
     ranks = Ranks(args)
-    head = measure(args, ranks, args.solver, resolution, args.steps, args.warmup, use_events)
+    head = measure(args, ranks, args.solver, resolution, args.steps, args.warmup, use_events,
+                   measure_cold=not os.environ.get("SFHIP_BENCH_CHILD"))
     head["live_traffic"] = counters_now["traffic"]
     head["live_valu"] = counters_now["valu"]
     bytes_per_update = 5 * 8.0 * NCONS[args.solver]
@@ -557,12 +618,17 @@ def main():
             plans["weak_scaling"] = default_resolution(world, base)
         if world == 8:
             plans["config2"] = 4 * base             # BASELINE.json configs[2]: 16384^2, 2048 x 16384 per rank
+            plans["config3"] = 2 * base             # BASELINE.json configs[3]: cbdgam_2d 8192^2, 1024 x 8192 per rank
         for name, n in plans.items():
+            kind = "gam" if name == "config3" else "iso"
             try:
-                run = measure(args, ranks, "iso", n, args.steps, min(args.warmup, 5), False)
-                extras[name] = summary(run, world, bytes_per_update)
+                run = measure(args, ranks, kind, n, args.steps, min(args.warmup, 5), False)
+                extras[name] = summary(run, world, 5 * 8.0 * NCONS[kind])
             except Exception as exc:  # an extra is a report, never a reason to lose the headline
                 extras[name] = dict(failed=repr(exc))
+        if "strong_scaling" in extras:
+            # BASELINE.json's metric is quoted on this series: the same object under the name that says so
+            extras["metric_config"] = extras["strong_scaling"]
 
     cpu = None
     if ranks.rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -574,7 +640,10 @@ def main():
     if ranks.rank == 0:
         setup, mesh = head["setup"], head["mesh"]
         line = {
-            "metric": f"zone-updates/sec (Mzps) fp64, {setup.solver}",
+            "metric": f"zone-updates/sec (Mzps) fp64, {setup.solver}" + ("" if world == 1 else (
+                "; value = the 4096^2 mesh over N GPUs (BASELINE.json's metric line)" if strong and args.resolution is None else
+                "; value = a fixed mesh over N GPUs" if strong else
+                "; value = weak scaling at 4096^2 zones per GPU, BASELINE.json's 4096^2-over-N-GPUs line is metric_config")),
             "value": round(head["mzps"], 2),
             "unit": "Mzps",
             "n_gpus": world,
@@ -600,13 +669,17 @@ def main():
                 "clock_ramp_steps": head["ramp_steps"],
                 "repeated_stage0": head["redos"],  # timed steps redone because the wavespeed fell below its filter
                 "transport": None if world == 1 else (
-                    ("RCCL called directly" if os.environ.get("SFHIP_HALO_TRANSPORT") == "rccl" else "RCCL through torch.distributed")
+                    ("RCCL called directly" + (" from C (step group)" if all(r.get("step_group") for r in head["proof"]) else "")
+                     if head["proof"][0].get("halo_transport") == "rccl" else "RCCL through torch.distributed")
                     if args.transport == "nccl" else "gloo, all ranks on cuda:0"),
             },
             "hbm_roofline_frac_whole_step": round(head["mzps"] * 1e6 * bytes_per_update / (world * HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline,
             "roofline_valu": valu,
             "cpu_baseline": cpu,
+            "cold_ms_per_step": None if head["cold_ms_per_step"] is None else round(head["cold_ms_per_step"], 4),
+            "cold_value": None if head["cold_ms_per_step"] is None else round(head["zones"] / head["cold_ms_per_step"] * 1e-3, 2),
+            "ranks": ranks_object(head["proof"], world, args.transport),
         }
         if kernel_ms:
             line["kernel_ms"] = kernel_ms

@@ -46,13 +46,19 @@ def test_bench_two_ranks_reports_both_scaling_series():
     assert line["scaling"] == "weak" and line["config"]["zones"] == 360 * 360  # 256 * sqrt(2), multiple of 8
     strong = line["strong_scaling"]
     assert strong["value"] > 0.0 and "256x256" in strong["workload"] and "128x256" in strong["workload"]
+    assert line["metric_config"] == strong and "metric_config" in line["metric"]
+    # the line says what ran: two ranks, here on one device over gloo (the driver's runs: N distinct devices, RCCL)
+    ranks = line["ranks"]
+    assert ranks["world_size"] == 2 and len(ranks["devices"]) == 2 and ranks["distinct_devices"] == 1
+    assert ranks["halo_transport"] == ["torch"] and ranks["rccl_comm_count"] is None
+    assert line["cold_ms_per_step"] > 0.0 and line["cold_value"] > 0.0
 
 
 @pytest.mark.gpu
 def test_bench_single_gpu_line_has_the_contract_fields():
     line = run_bench("--steps", "4", "--warmup", "2", "--resolution", "512", "--cpu-seconds", "1", "--no-traffic-pass")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cold_ms_per_step", "ranks"):
         assert key in line, key
     assert line["dtype"] == "f64" and line["data"] == "synthetic" and line["vs_baseline"] is None
     r = line["roofline"]
