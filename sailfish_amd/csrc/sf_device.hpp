@@ -87,6 +87,21 @@ __global__ void step_bookkeeping_kernel(double *zero_ptr, double *host_out, doub
 __device__ __forceinline__ double min2(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double max2(double a, double b) { return a > b ? a : b; }
 
+// v_min_f64 / v_max_f64 as single instructions.  __builtin_fmin / fmax are llvm.minnum / maxnum, whose operands the
+// compiler first "canonicalises" (v_max_f64 x, x, x: quiets a signalling NaN) whenever it cannot prove them to be
+// results of arithmetic -- values that arrived through a lane move, a loop-carried register or a kernel argument:
+// ten extra instructions per row of the cbdiso_2d march.  No operand here is ever a signalling NaN, and the
+// instruction treats quiet NaNs exactly as the builtin does (the other operand is returned).
+__device__ __forceinline__ double min_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double min_abs_f64(double a, double b) { double r; asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; } // min(|a|, |b|)
+__device__ __forceinline__ double min_abs2_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; } // min(a, |b|)
+__device__ __forceinline__ double min0_f64(double a) { double r; asm("v_min_f64 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }           // min(a, 0)
+__device__ __forceinline__ double max0_f64(double a) { double r; asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }           // max(a, 0)
+// the second operand wave-uniform (scalar registers): no vector copy of it
+__device__ __forceinline__ double max_s_f64(double a, double s) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
+__device__ __forceinline__ double min_abs_s_f64(double a, double s) { double r; asm("v_min_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "s"(s)); return r; } // min(|a|, s)
+
 // Generalised minmod slope, cbdiso_2d.c:23-29 / cbdgam_2d.c:27-33.
 // The reference's 0.25*|sgn a + sgn b|*(sgn a + sgn c)*min|.| is +-min when the
 // three sign bits agree and a signed zero otherwise; all factors are powers of
@@ -115,7 +130,7 @@ __device__ __forceinline__ double plm2(double yl, double y0, double yr)
     constexpr double theta2 = 2.0 * (THETA10 / 10.0);
     double d1 = y0 - yl;
     double d2 = yr - y0;
-    double m = __builtin_fmin(__builtin_fmin(fabs(d1), fabs(d2)) * theta2, fabs(yr - yl));
+    double m = min_abs2_f64(min_abs_f64(d1, d2) * theta2, yr - yl);
     int sx = __double2hiint(d1) ^ __double2hiint(d2);
     asm("" : "+v"(sx)); // keep the sign test on the high dwords (the optimiser widens it to a 64-bit xor + compare)
     bool same = sx >= 0;
@@ -129,7 +144,7 @@ template <int THETA10>
 __device__ __forceinline__ double plm2_diffs(double d1, double d2)
 {
     constexpr double theta2 = 2.0 * (THETA10 / 10.0);
-    double m = __builtin_fmin(__builtin_fmin(fabs(d1), fabs(d2)) * theta2, fabs(d1 + d2));
+    double m = min_abs2_f64(min_abs_f64(d1, d2) * theta2, d1 + d2);
     int sx = __double2hiint(d1) ^ __double2hiint(d2);
     asm("" : "+v"(sx));
     bool same = sx >= 0;
@@ -152,10 +167,17 @@ __device__ __forceinline__ double fast_rcp(double d)
 #if defined(SFHIP_RSQ_RAW)
     return r;
 #endif
+#if defined(SFHIP_RCP_TWO_NEWTON)  // rounds 1 and 2: two quadratic steps, one instruction more
     double e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(r, e, r);
+#else
+    // one cubically convergent step, r (1 + e + e^2), e = 1 - d r: the seed's 2^-24 becomes 2^-72 before rounding
+    double e = __builtin_fma(-d, r, 1.0);
+    double t = __builtin_fma(e, e, e);
+    return __builtin_fma(r, t, r);
+#endif
 }
 
 // 1/sqrt(x), x > 0: one cubically convergent step, y (1 + e/2 + 3 e^2/8), e = 1 - x y^2
@@ -181,6 +203,21 @@ __device__ __forceinline__ double sqrt_from_rsqrt(double x, double y)
     double s = x * y;
     double r = __builtin_fma(-s, s, x);
     return __builtin_fma(r, 0.5 * y, s);
+}
+
+// sqrt(x), x > 0, where 1/sqrt(x) itself is not needed: the coupled (Goldschmidt) iteration from the hardware seed
+// y0 ~ 1/sqrt(x) -- g = x y0 -> sqrt(x), h = y0/2 -> 1/(2 sqrt(x)), one joint step (2^-24 -> 2^-47), then g corrected
+// with its own residual -- 8 instructions against the 10 of fast_rsqrt + sqrt_from_rsqrt; within 1 ulp.
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
 }
 
 // ---------------------------------------------------------------------------

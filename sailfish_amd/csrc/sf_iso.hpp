@@ -113,7 +113,7 @@ __device__ __forceinline__ void iso_sound_fast(const IsoParams &P, const Mass *m
     if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; q += m[0].mass * fast_rsqrt(d * d + c0); }
     if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; q += m[1].mass * fast_rsqrt(d * d + c1); }
     cs2 = q * P.inv_mach2;
-    cs = sqrt_from_rsqrt(cs2, fast_rsqrt(cs2));
+    cs = fast_sqrt(cs2);
 }
 
 // HLLE flux through one face, cbdiso_2d.c:285-380.  DIR 0: x-face, 1: y-face.
@@ -121,35 +121,36 @@ template <int DIR>
 __device__ __forceinline__ void iso_hlle(const double *pl, const double *pr, double cs2, double cs, double *f)
 {
 #pragma clang fp contract(fast)
-    double ul1 = pl[1] * pl[0], ul2 = pl[2] * pl[0];
-    double ur1 = pr[1] * pr[0], ur2 = pr[2] * pr[0];
-    double vl = pl[1 + DIR], vr = pr[1 + DIR];
-    double prl = pl[0] * cs2, prr = pr[0] * cs2;
-    double fl0 = vl * pl[0], fr0 = vr * pr[0];
-    double fl1 = vl * ul1, fr1 = vr * ur1;
-    double fl2 = vl * ul2, fr2 = vr * ur2;
-    if (DIR == 0) { fl1 += prl; fr1 += prr; }
-    else          { fl2 += prl; fr2 += prr; }
+    // F = (Fl ap - Fr am - (Ul - Ur) ap am) / (ap - am), regrouped by side:
+    //   F = wl (Fl - am Ul) - wr (Fr - ap Ur),  wl = ap / (ap - am), wr = am / (ap - am),
+    // and Fl - am Ul = (vl - am) Ul + p e: per side one factor A = wl (vl - am), B = wr (vr - ap) for the advected
+    // part of all three components, and one pressure term cs2 (wl rho_l - wr rho_r) on the normal momentum.
+    // Same value as the textbook form up to rounding; 11 instructions per face fewer.
+    const double ul1 = pl[1] * pl[0], ul2 = pl[2] * pl[0];
+    const double ur1 = pr[1] * pr[0], ur2 = pr[2] * pr[0];
+    const double vl = pl[1 + DIR], vr = pr[1 + DIR];
     // min(vl - cs, vr - cs) = min(vl, vr) - cs exactly (rounding is monotone): one subtraction instead of two
-    double am = __builtin_fmin(0.0, __builtin_fmin(vl, vr) - cs);
-    double ap = __builtin_fmax(0.0, __builtin_fmax(vl, vr) + cs);
-    // F = (Fl ap - Fr am - (Ul - Ur) ap am) / (ap - am) with the three weights formed once per face
-    double rden = fast_rcp(ap - am);
-    double wl = ap * rden, wr = am * rden, wd = wl * am;
-    f[0] = fl0 * wl - fr0 * wr - (pl[0] - pr[0]) * wd;
-    f[1] = fl1 * wl - fr1 * wr - (ul1 - ur1) * wd;
-    f[2] = fl2 * wl - fr2 * wr - (ul2 - ur2) * wd;
+    const double am = min0_f64(min_f64(vl, vr) - cs);
+    const double ap = max0_f64(max_f64(vl, vr) + cs);
+    const double rden = fast_rcp(ap - am);
+    const double wl = ap * rden, wr = am * rden;
+    const double A = wl * (vl - am), B = wr * (vr - ap);
+    const double pt = cs2 * (wl * pl[0] - wr * pr[0]);
+    f[0] = A * pl[0] - B * pr[0];
+    f[1] = A * ul1 - B * ur1;
+    f[2] = A * ul2 - B * ur2;
+    f[1 + DIR] += pt;
 }
 
 // Primitive recovery with floors, cbdiso_2d.c:268-283 (the division through a ~1-ulp reciprocal: fast_rcp).
 __device__ __forceinline__ void iso_c2p(const double *u, double vmax, double dfloor, double *p)
 {
 #pragma clang fp contract(fast)
-    double rho = __builtin_fmax(u[0], dfloor);
+    double rho = max_s_f64(u[0], dfloor);
     double rinv = fast_rcp(rho);
     p[0] = rho;
-    p[1] = copysign(__builtin_fmin(fabs(u[1] * rinv), vmax), u[1]);
-    p[2] = copysign(__builtin_fmin(fabs(u[2] * rinv), vmax), u[2]);
+    p[1] = copysign(min_abs_s_f64(u[1] * rinv, vmax), u[1]);
+    p[2] = copysign(min_abs_s_f64(u[2] * rinv, vmax), u[2]);
 }
 
 // One point mass: gravity + sink, cbdiso_2d.c:97-175.  Accumulates into dc.
@@ -225,7 +226,7 @@ __device__ __forceinline__ void iso_buffer(const IsoParams &P, double xc, double
         double rinv = fast_rsqrt(rc2);
         double rc = sqrt_from_rsqrt(rc2, rinv);
         double vk2 = P.buf_mc * rinv;                           // central_mass / rc
-        double vk = sqrt_from_rsqrt(vk2, fast_rsqrt(vk2));
+        double vk = fast_sqrt(vk2);
         double pk = P.buf_sd * vk * rinv;                       // sigma v_kep / rc
         double br = P.buf_rate_scale * (rc - P.buf_ron) * P.dt; // driving_rate omega (rc-ron)/(rout-ron) dt
         dc[0] -= (u[0] - P.buf_sd) * br;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                             if (FULL || P.m[0].mass > 0.0) c2e += P.m[0].mass * y0;
                             if (FULL || P.m[1].mass > 0.0) c2e += P.m[1].mass * y1;
                             c2e *= P.inv_mach2;
-                            cse = sqrt_from_rsqrt(c2e, fast_rsqrt(c2e));
+                            cse = fast_sqrt(c2e);
                         }
                     } else {
                         iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
@@ -525,7 +526,16 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         iso_row_leaves(pb, gxb, sxx, sxy, quarter, pmx, txx, txy);
         enter(pn);
         __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
-#if defined(SFHIP_DIAG_NO_STORE)  // diagnosis builds only: what the stores cost
+#if defined(SFHIP_DIAG_STORE_EVERY)  // diagnosis builds only (WRONG results): the same bytes, stored every Nth iteration
+        if (upd && store_lane && (r % SFHIP_DIAG_STORE_EVERY) == 0) {
+            for (int k = 0; k < SFHIP_DIAG_STORE_EVERY; ++k) {
+                const int rr = r - 2 - k < NG ? NG : r - 2 - k; // (never below the first interior row)
+                const long c = (long)rr * si + (long)J * sj;
+                pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2];
+            }
+        }
+        if (false) {
+#elif defined(SFHIP_DIAG_NO_STORE)  // diagnosis builds only: what the stores cost
         if (upd && store_lane && out[0] < -1e300) {
 #else
         if (upd && store_lane) {
