@@ -47,6 +47,15 @@ __device__ __forceinline__ double from_lane_above(double x) // value held by lan
 // (The same moves through the LDS crossbar -- ds_bpermute_b32, not a VALU instruction -- were measured: 2-3 %
 // slower; the stage kernels do not have the lgkm latency to spare at three waves per SIMD.)
 
+// A mesh coordinate x0 + idx * dx in the reference's two roundings (cbdiso_2d.c:446-454: plain C, no fused
+// multiply-add), also where the caller's other arithmetic is allowed to contract.
+__device__ __forceinline__ double mesh_coord(double x0, double idx, double dx)
+{
+#pragma clang fp contract(off)
+    const double t = idx * dx;
+    return x0 + t;
+}
+
 // A wave-uniform double moved to scalar registers: a plain operand of vector instructions from then on.
 __device__ __forceinline__ double uniform_value(double x)
 {

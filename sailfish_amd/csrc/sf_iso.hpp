@@ -19,6 +19,9 @@
 
 namespace sf {
 
+constexpr int ROW_ENTRY = 6;        // doubles per entry of a marching wave's row table (5 used; 48-byte entries)
+constexpr int ROW_TABLE_SPAN = 60;  // rows between two refills of the 64-entry table (an iteration looks back 2 rows)
+
 struct IsoParams {
     int ni, nj;                 // interior zones of the patch
     double xl, yl, dx, dy;      // patch origin and spacing (dx = (xr-xl)/ni on the host, cbdiso_2d.c:440)
@@ -103,15 +106,16 @@ __device__ __attribute__((noinline)) double iso_exact_speed(const IsoParams *Pk,
 // `c0`, `c1` are the lane-invariant parts (y - y_p)^2 + rs_p^2 of the two masses.
 // FULL: the caller has established (once, on the host) that the EOS is locally isothermal and both
 // masses are positive, so the tests below are compile-time true; the arithmetic is the same.
+// `d0`, `d1`: x - x_p of the two masses (wave-uniform along a row: the march reads them from its row table).
 template <bool FULL = false>
-__device__ __forceinline__ void iso_sound_fast(const IsoParams &P, const Mass *m, double x, double c0, double c1,
+__device__ __forceinline__ void iso_sound_fast(const IsoParams &P, const Mass *m, double d0, double d1, double c0, double c1,
                                                double &cs2, double &cs)
 {
 #pragma clang fp contract(fast)
     if (!FULL && !P.eos_local) { cs2 = P.cs2_uniform; cs = P.cs_uniform; return; }
     double q = 0.0;
-    if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; q += m[0].mass * fast_rsqrt(d * d + c0); }
-    if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; q += m[1].mass * fast_rsqrt(d * d + c1); }
+    if (FULL || m[0].mass > 0.0) q += m[0].mass * fast_rsqrt(d0 * d0 + c0);
+    if (FULL || m[1].mass > 0.0) q += m[1].mass * fast_rsqrt(d1 * d1 + c1);
     cs2 = q * P.inv_mach2;
     cs = fast_sqrt(cs2);
 }
@@ -154,18 +158,17 @@ __device__ __forceinline__ void iso_c2p(const double *u, double vmax, double dfl
 }
 
 // One point mass: gravity + sink, cbdiso_2d.c:97-175.  Accumulates into dc.
-// `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed; `sink_reach2` =
+// `ddx` = x - x_p (uniform along a row); `ddy` = y - y_p and `cy` = ddy^2 + rs^2 are lane-invariant and precomputed; `sink_reach2` =
 // (4 r_sink)^2 + rs^2.  `cold` points at the same mass in memory: what only the sink branch needs
 // (a handful of waves per launch) is loaded there, on demand, instead of occupying SGPRs throughout.
 // `ds`: where the sink's contributions go (the diagnostics keep gravity and accretion apart); `dc` when null.
-__device__ __forceinline__ double iso_mass_source(double mx, double mmass, double sink_reach2, const Mass *cold,
-                                                  double x1, double ddy, double cy, double dt,
+__device__ __forceinline__ double iso_mass_source(double ddx, double mmass, double sink_reach2, const Mass *cold,
+                                                  double ddy, double cy, double dt,
                                                   const double *prim, double *dc, double *ds = nullptr)
 {
 #pragma clang fp contract(fast)
     if (!ds) ds = dc;
     double sigma = prim[0];
-    double ddx = x1 - mx;
     double r2s = ddx * ddx + cy;
     const double y = fast_rsqrt(r2s); // 1/sqrt(r^2 + rs^2): returned, the wavespeed epilogue reuses it
     double fnum = sigma * mmass * (y * y * y) * dt; // pow(r^2 + rs^2, -1.5) of the reference
@@ -212,7 +215,7 @@ __device__ __forceinline__ void iso_mass_source(const Mass &m, double x1, double
                                                 const double *prim, double *dc, double *ds = nullptr)
 {
     double rs4 = 4.0 * m.sink_radius;
-    iso_mass_source(m.x, m.mass, rs4 * rs4 + m.rsoft * m.rsoft, &m, x1, ddy, cy, dt, prim, dc, ds);
+    iso_mass_source(x1 - m.x, m.mass, rs4 * rs4 + m.rsoft * m.rsoft, &m, ddy, cy, dt, prim, dc, ds);
 }
 
 // Keplerian buffer, cbdiso_2d.c:213-246
@@ -280,7 +283,10 @@ __device__ __forceinline__ void iso_row_leaves(const double *pb, const double *g
 //       (tests/test_hip_solver.py::test_full_physics_instantiation).  One run uses one instantiation
 //       throughout, on every patch and rank.
 template <int WS, bool UN, bool FULL>
-__global__ __launch_bounds__(256, 3) void iso_stage_kernel(
+#if !defined(SFHIP_ISO_A0_WAVES)
+#define SFHIP_ISO_A0_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (WS == 0 && !UN) ? SFHIP_ISO_A0_WAVES : 3) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
 {
@@ -311,8 +317,8 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     const long col = Jld * sj;
     const bool store_lane = lane >= HALO && lane < WAVE - HALO && J < nj + NG;
     const int jz = J - NG; // zone index in j (halo lanes may be out of range; values unused)
-    const double yc = P.yl + (jz + 0.5) * P.dy;
-    const double yf = P.yl + (double)jz * P.dy; // lower y-face of this lane's zone
+    const double yc = mesh_coord(P.yl, jz + 0.5, P.dy);
+    const double yf = mesh_coord(P.yl, (double)jz, P.dy); // lower y-face of this lane's zone
 
     // rows (guard-inclusive index) updated by this wave
     const int I0 = NG + P.i_begin + chunk * P.rows_per_chunk;
@@ -374,6 +380,22 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
 #pragma unroll
         for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pa[q]));
     }
+    // Row table.  What a row contributes through its x-coordinate alone -- the face and centre positions and their
+    // distances to the two masses -- is the same for all 64 lanes, but there is no scalar fp64 unit: formed in the
+    // march it costs every lane 16 vector instructions per row.  Instead lane l forms the entry of row T - 2 + l,
+    // once per 60 rows, into this wave's 64 entries of LDS, and the march reads the two entries an iteration needs
+    // (same address in every lane: a broadcast, no VALU).  The operations are the ones the march performed itself.
+    __shared__ double row_table[4][WAVE][ROW_ENTRY];
+    double (*const tab)[ROW_ENTRY] = row_table[threadIdx.x >> 6];
+    auto fill_rows = [&](int T) { // entries of rows T-2 ... T+61, slot = row & 63
+        const int rho = T - 2 + lane;
+        const double xfr = mesh_coord(P.xl, (double)(rho - NG), P.dx);  // lower x-face of row rho
+        const double xcr = mesh_coord(P.xl, (rho - NG) + 0.5, P.dx);    // its centre
+        double *e = tab[rho & (WAVE - 1)];
+        e[0] = xfr - P.m[0].x; e[1] = xfr - P.m[1].x;
+        e[2] = xcr - P.m[0].x; e[3] = xcr - P.m[1].x;
+        e[4] = xcr;
+    };
     constexpr bool want_un = UN;
     const long ucol = (long)(J < nj + 2 * NG ? J : nj + 2 * NG - 1) * sj;
     auto enter = [&](const double *row_in) { // a row enters the window: its y-slopes from the neighbouring lanes
@@ -410,13 +432,30 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
     // the requested row has been put to its first use (its y-slopes, which is what makes the compiler
     // wait for it there), and the next requests follow as the first thing of the next iteration: whatever a
     // wait drains is then most of an iteration old.
+    int refill = I0 + 1; // the iteration that next renews the row table
 #pragma unroll 1
     for (int r = I0 + 1; r <= I1 + 1; ++r) {
+        if (r == refill) { fill_rows(r); refill += ROW_TABLE_SPAN; }
+        // (read here, with the global requests, a whole face block before their first use: the march has no other
+        // wave's work to hide an LDS round trip behind)
+        const double *ebp = tab[(r - 1) & (WAVE - 1)]; // row r-1: faces
+        const double *eap = tab[(r - 2) & (WAVE - 1)]; // row r-2: the update
+        const double eb[4] = {ebp[0], ebp[1], ebp[2], ebp[3]};
+        const double ea[5] = {0.0, 0.0, eap[2], eap[3], eap[4]};
         const bool upd = r - 2 >= I0;
         if (upd && want_un) {
             // u^n of the row updated in this iteration: in flight during both face blocks
             const double *us = unsrc + (long)(r - 2) * si + ucol;
+#if defined(SFHIP_DIAG_COALESCED)
+            {
+                const long e0 = (long)(J - lane) * 3 + lane, last = si - 1;
+                us -= ucol;
+                un[0] = us[e0 < last ? e0 : last]; un[1] = us[e0 + 64 < last ? e0 + 64 : last];
+                un[2] = us[e0 + 128 < last ? e0 + 128 : last];
+            }
+#else
             un[0] = us[0]; un[1] = us[1]; un[2] = us[2];
+#endif
         }
         { // (the last iteration's request is never consumed: a clamped, valid row; saves a branch)
 #if defined(SFHIP_DIAG_SAME_ROW)  // diagnosis builds only: every request hits the cache (what the loads' latency costs)
@@ -424,15 +463,45 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
 #else
             const double *src = row(r + 1);
 #endif
+#if defined(SFHIP_DIAG_COALESCED)  // diagnosis builds only (WRONG data): the same bytes, lane-contiguous
+            {   // (element index within the row, clamped to the row: the last row of the array has nothing behind it)
+                const long e0 = (long)(J - lane) * 3 + lane, last = si - 1;
+                src -= col;
+                pn[0] = src[e0 < last ? e0 : last]; pn[1] = src[e0 + 64 < last ? e0 + 64 : last];
+                pn[2] = src[e0 + 128 < last ? e0 + 128 : last];
+            }
+#else
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0); // keep the requests first (the scheduler would sink them by ~150 instructions)
+#if defined(SFHIP_DIAG_NO_COMPUTE)  // diagnosis builds only (WRONG results): the march's memory traffic without its arithmetic
+        {
+            double o[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                o[q] = pa[q] + (want_un ? un[q] : 0.0);
+                pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (upd && store_lane) {
+#if defined(SFHIP_DIAG_COALESCED)
+                const long e0 = (long)(J - lane) * 3 + lane, last = si - 1; // (clamped to the row, as the loads)
+                double *w = pwr + (long)(r - 2) * si;
+                w[e0 < last ? e0 : last] = o[0]; w[e0 + 64 < last ? e0 + 64 : last] = o[1];
+                w[e0 + 128 < last ? e0 + 128 : last] = o[2];
+#else
+                const long c = (long)(r - 2) * si + (long)J * sj;
+                pwr[c] = o[0]; pwr[c + 1] = o[1]; pwr[c + 2] = o[2];
+#endif
+            }
+            continue;
+        }
+#endif
         // row r-1 now has both neighbours: x-slopes and strain (cbdiso_2d.c:248-263)
         double gxb[3], sxx, syy, sxy;
         iso_row_slopes(pa, pb, pc, gyb, visc, hidx, hidy, gxb, sxx, syy, sxy);
 
-        const double xf = P.xl + (double)(r - 1 - NG) * P.dx;       // lower x-face of row r-1
-        const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;      // centre of row r-1
 
         // Both faces are evaluated in every iteration, so that the fluxes are plain locals and the
         // loop-carried `acc` is written unconditionally.  The first iteration's x-face (row I0-1, whose
@@ -444,7 +513,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
             double ppx[3], c2, cs;
 #pragma unroll
             for (int q = 0; q < 3; ++q) ppx[q] = pb[q] - quarter * gxb[q];
-            iso_sound_fast<FULL>(P, P.m, xf, cyc0, cyc1, c2, cs);
+            iso_sound_fast<FULL>(P, P.m, eb[0], eb[1], cyc0, cyc1, c2, cs); // at the lower x-face of row r-1
             iso_hlle<0>(pmx, ppx, c2, cs, F);
             if (visc) {
                 F[1] -= hnu * (txx + pb[0] * sxx);
@@ -462,7 +531,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                 pmy[q] = from_lane_below(pb[q] + quarter * gyb[q]);
                 ppy[q] = pb[q] - quarter * gyb[q];
             }
-            iso_sound_fast<FULL>(P, P.m, xcb, cyf0, cyf1, c2, cs);
+            iso_sound_fast<FULL>(P, P.m, eb[2], eb[3], cyf0, cyf1, c2, cs); // at the centre of row r-1 in x
             iso_hlle<1>(pmy, ppy, c2, cs, G);
             if (visc) {
                 double tyx = pb[0] * sxy, tyy = pb[0] * syy;
@@ -475,12 +544,12 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
         }
         if (upd) {
             // update row r-2 (cbdiso_2d.c:588-602)
-            const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
+            const double xc = ea[4];
             double u[3] = {pa[0], pa[1] * pa[0], pa[2] * pa[0]};
             double dc[3] = {0.0, 0.0, 0.0};
             iso_buffer<FULL>(P, xc, yc, yc2, u, dc);
-            const double y0 = iso_mass_source(P.m[0].x, P.m[0].mass, reach0, &Pk->m[0], xc, dyc0, cyc0, P.dt, pa, dc);
-            const double y1 = iso_mass_source(P.m[1].x, P.m[1].mass, reach1, &Pk->m[1], xc, dyc1, cyc1, P.dt, pa, dc);
+            const double y0 = iso_mass_source(ea[2], P.m[0].mass, reach0, &Pk->m[0], dyc0, cyc0, P.dt, pa, dc);
+            const double y1 = iso_mass_source(ea[3], P.m[1].mass, reach1, &Pk->m[1], dyc1, cyc1, P.dt, pa, dc);
 #pragma unroll
             for (int q = 0; q < 3; ++q) u[q] += dc[q] + tot[q];
             if (want_un) {
@@ -512,7 +581,7 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
                             cse = fast_sqrt(c2e);
                         }
                     } else {
-                        iso_sound_fast(P, P.mw, xc, cyw0, cyw1, c2e, cse);
+                        iso_sound_fast(P, P.mw, xc - P.mw[0].x, xc - P.mw[1].x, cyw0, cyw1, c2e, cse);
                     }
                     if (!((vm + cse) * (1.0 + 1e-9) < athr)) { // unordered passes: a NaN must reach the fold
                         double sp = iso_exact_speed(Pk, xc, yc, vx, vy);
@@ -544,7 +613,11 @@ __global__ __launch_bounds__(256, 3) void iso_stage_kernel(
             const long c = (long)(r - 2) * si + (long)(J - lane) * sj + lane;
             pwr[c] = out[0]; pwr[c + 64] = out[1]; pwr[c + 128] = out[2];
 #else
+#if defined(SFHIP_DIAG_SAME_ROW_STORE)  // diagnosis builds only (WRONG results): every store hits one of two cached rows
+            const long c = (long)(I0 + (r & 1)) * si + (long)J * sj;
+#else
             const long c = (long)(r - 2) * si + (long)J * sj;
+#endif
             // (non-temporal stores were measured: -1.5 % on the a = 0 stage alone, nothing on the RK2 pair)
             pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2];
 #endif
