@@ -14,6 +14,9 @@ constexpr int WAVE = 64;       // CDNA wavefront
 constexpr int HALO = 2;        // lanes lost on each side of a wave's column strip
 constexpr int STRIP = WAVE - 2 * HALO; // output columns per wave (60)
 
+constexpr int ROW_ENTRY = 6;        // doubles per entry of a marching wave's row table (5 used; 48-byte entries)
+constexpr int ROW_TABLE_SPAN = 60;  // rows between two refills of the 64-entry table (an iteration looks back 2 rows)
+
 // Point mass as the reference passes it: 8 doubles + sink model (cbdiso_2d.c:42-52).
 struct Mass {
     double x, y, vx, vy, mass, rsoft, sink_rate, sink_radius;

@@ -170,14 +170,15 @@ __device__ __forceinline__ void gam_mass_source(const Mass &m, double x1, double
 // 1/sqrt(sum_p m_p r_p^-3) at a point; c0, c1 = (y - y_p)^2 + 1e-12 precomputed per lane.
 // Multiplying sqrt(p/sigma) by it gives disk_height (cbdgam_2d.c:75-106).
 // FULL: both masses are known (on the host) to be positive, see gam_stage_kernel.
+// `d0`, `d1`: x - x_p of the two masses (uniform along a row: the march reads them from its row table, sf_iso.hpp).
 template <bool FULL = false>
-__device__ __forceinline__ double gam_inv_omega_fast(const Mass *m, double x, double c0, double c1)
+__device__ __forceinline__ double gam_inv_omega_fast(const Mass *m, double d0, double d1, double c0, double c1)
 {
 #pragma clang fp contract(fast)
     // (explicit operations: the bring-up before the march and the march itself evaluate this for the same zone)
     double om2 = 0.0;
-    if (FULL || m[0].mass > 0.0) { double d = x - m[0].x; double y = fast_rsqrt(__builtin_fma(d, d, c0)); om2 = __builtin_fma(m[0].mass, y * y * y, om2); }
-    if (FULL || m[1].mass > 0.0) { double d = x - m[1].x; double y = fast_rsqrt(__builtin_fma(d, d, c1)); om2 = __builtin_fma(m[1].mass, y * y * y, om2); }
+    if (FULL || m[0].mass > 0.0) { double y = fast_rsqrt(__builtin_fma(d0, d0, c0)); om2 = __builtin_fma(m[0].mass, y * y * y, om2); }
+    if (FULL || m[1].mass > 0.0) { double y = fast_rsqrt(__builtin_fma(d1, d1, c1)); om2 = __builtin_fma(m[1].mass, y * y * y, om2); }
     return fast_rsqrt(om2);
 }
 
@@ -189,8 +190,8 @@ __device__ __forceinline__ void gam_c2p(const double *u, double gm1, double vmax
     // max2(pressure_floor, .) of the reference: a NaN energy stays a NaN pressure (fmax would floor it)
     double pres = (u[3] - 0.5 * (u[1] * u[1] + u[2] * u[2]) * rinv) * gm1;
     pres = pres < pfloor ? pfloor : pres;
-    double vx = copysign(__builtin_fmin(fabs(u[1] * rinv), vmax), u[1]);
-    double vy = copysign(__builtin_fmin(fabs(u[2] * rinv), vmax), u[2]);
+    double vx = copysign(min_abs_s_f64(u[1] * rinv, vmax), u[1]);
+    double vy = copysign(min_abs_s_f64(u[2] * rinv, vmax), u[2]);
     double rho = u[0];
     if (u[0] < dfloor) { rho = dfloor; vx = 0.0; vy = 0.0; pres = pfloor; }
     p[0] = rho; p[1] = vx; p[2] = vy; p[3] = pres;
@@ -203,12 +204,18 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
                                                double inv_gm1, double *fR, double *fL)
 {
 #pragma clang fp contract(fast)
-    double ul[4], ur[4], fl[4], fr[4], du[4];
+    // (Fl ap - Fr am - (Ul - Ur) ap am) / (ap - am) with the three weights formed once per flux.  The regrouping by
+    // side that iso_hlle uses (sf_iso.hpp; 12 instructions per face fewer here) was built and withdrawn: equal to
+    // rounding on every test, but the free-running 384^2 disk, whose domain corners sit on the pressure floor next to
+    // zones of order-one pressure from t ~ 1.3 on (the reference scheme's own weak spot), then blew up at t = 1.42
+    // where this form carries on -- and the step rate gained 1 %.
+    double ul[4], ur[4];
     ul[0] = pm[0]; ul[1] = pm[1] * pm[0]; ul[2] = pm[2] * pm[0];
     ul[3] = pm[3] * inv_gm1 + 0.5 * pm[0] * (pm[1] * pm[1] + pm[2] * pm[2]);
     ur[0] = pp[0]; ur[1] = pp[1] * pp[0]; ur[2] = pp[2] * pp[0];
     ur[3] = pp[3] * inv_gm1 + 0.5 * pp[0] * (pp[1] * pp[1] + pp[2] * pp[2]);
-    double vl = pm[1 + DIR], vr = pp[1 + DIR];
+    const double vl = pm[1 + DIR], vr = pp[1 + DIR];
+    double fl[4], fr[4], du[4];
     fl[0] = vl * ul[0]; fl[1] = vl * ul[1]; fl[2] = vl * ul[2]; fl[3] = vl * (ul[3] + pm[3]);
     fr[0] = vr * ur[0]; fr[1] = vr * ur[1]; fr[2] = vr * ur[2]; fr[3] = vr * (ur[3] + pp[3]);
     fl[1 + DIR] += pm[3];
@@ -217,24 +224,17 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
     for (int q = 0; q < 4; ++q) du[q] = ul[q] - ur[q];
     // min(vl - cs, vr - cs) = min(vl, vr) - cs exactly (rounding is monotone): the extremes of the two normal
     // velocities are formed once per face, each flux subtracts / adds its own sound speed
-    const double vmin = __builtin_fmin(vl, vr), vmax = __builtin_fmax(vl, vr);
-    {
-        double am = __builtin_fmin(0.0, vmin - csL);
-        double ap = __builtin_fmax(0.0, vmax + csL);
-        // (Fl ap - Fr am - dU ap am) / (ap - am) with the three weights formed once per flux
-        double rden = fast_rcp(ap - am);
-        double wl = ap * rden, wr = am * rden, wd = wl * am;
+    const double vlo = min_f64(vl, vr), vhi = max_f64(vl, vr);
+    auto flux = [&](double cs, double *f) {
+        const double am = min0_f64(vlo - cs);
+        const double ap = max0_f64(vhi + cs);
+        const double rden = fast_rcp(ap - am);
+        const double wl = ap * rden, wr = am * rden, wd = wl * am;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fR[q] = fl[q] * wl - fr[q] * wr - du[q] * wd;
-    }
-    {
-        double am = __builtin_fmin(0.0, vmin - csR);
-        double ap = __builtin_fmax(0.0, vmax + csR);
-        double rden = fast_rcp(ap - am);
-        double wl = ap * rden, wr = am * rden, wd = wl * am;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fL[q] = fl[q] * wl - fr[q] * wr - du[q] * wd;
-    }
+        for (int q = 0; q < 4; ++q) f[q] = fl[q] * wl - fr[q] * wr - du[q] * wd;
+    };
+    flux(csL, fR);
+    flux(csR, fL);
 }
 
 // One point mass, cbdgam_2d.c:108-203.  `ddy`, `cy` = ddy^2 (+ rs^2 when softening is constant) per lane;
@@ -243,14 +243,13 @@ __device__ __forceinline__ void gam_hlle2_fast(const double *pm, const double *p
 // sink interior needs (loaded there, on demand, instead of occupying SGPRs throughout the march).
 template <bool FULL = false>
 __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double near2, const Mass *cold,
-                                                     double x1, double ddy, double dt,
+                                                     double ddx, double ddy, double dt,
                                                      const double *prim, double eps, double h, double *u,
                                                      int constant_softening)
 {
 #pragma clang fp contract(fast)
     if (!FULL && (m.sink_model < 1 || m.sink_model > 3)) return; // inactive: no gravity either (cbdgam_2d.c:194-201)
     double sigma = prim[0];
-    double ddx = x1 - m.x;
     double r2 = ddx * ddx + ddy * ddy;
     double r_sink = m.sink_radius;
     double rs4 = 4.0 * r_sink;
@@ -321,7 +320,7 @@ __device__ __forceinline__ void gam_buffer_fast(const GamParams &P, double xc, d
         double rinv = fast_rsqrt(rc2);
         double rc = sqrt_from_rsqrt(rc2, rinv);
         double vk2 = P.buf_mc * rinv;
-        double pf = P.buf_sd * sqrt_from_rsqrt(vk2, fast_rsqrt(vk2)) * rinv; // sigma v_kep / rc
+        double pf = P.buf_sd * fast_sqrt(vk2) * rinv; // sigma v_kep / rc
         double px = -pf * yc, py = pf * xc;
         double en = P.buf_e0 + 0.5 * (px * px + py * py) * P.inv_buf_sd;
         double br = P.buf_rate_scale * (rc - P.buf_ron) * P.dt;
@@ -345,7 +344,7 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
     }
     double vx = prim[1], vy = prim[2];
     double ek = 0.5 * (vx * vx + vy * vy);
-    ec = __builtin_fmax(ec, ek * P.mach_floor_scale);
+    ec = max_f64(ec, ek * P.mach_floor_scale);
     u[3] += sigma * (ec - eps);
 }
 
@@ -359,7 +358,7 @@ __device__ __forceinline__ void gam_cooling_fast(const GamParams &P, const doubl
 template <bool FULL>
 __device__ __forceinline__ void gam_row_state(const GamParams &P, const double *pa, const double *pb, const double *pc,
                                               const double *gyb, bool visc, bool hvar, double hidx, double hidy,
-                                              double xcb, double oyc0, double oyc1, double *gxb, double &sxx,
+                                              double dxc0, double dxc1, double oyc0, double oyc1, double *gxb, double &sxx,
                                               double &syy, double &sxy, double &qhb, double &csb, double &nub)
 {
 #pragma unroll
@@ -373,10 +372,10 @@ __device__ __forceinline__ void gam_row_state(const GamParams &P, const double *
         sxy = __builtin_fma(gxb[2], hidx, gyb[1] * hidy);
     }
     const double prb = pb[3] * fast_rcp(pb[0]);
-    qhb = sqrt_from_rsqrt(prb, fast_rsqrt(prb));
+    qhb = fast_sqrt(prb);
     csb = qhb * P.sqrt_gamma;
     nub = 0.0;
-    if (visc) nub = P.half_alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, xcb, oyc0, oyc1) : 1.0) * csb;
+    if (visc) nub = P.half_alpha * (hvar ? qhb * gam_inv_omega_fast<FULL>(P.m, dxc0, dxc1, oyc0, oyc1) : 1.0) * csb;
 }
 
 // FULL: the benchmark's physics, established on the host -- alpha viscosity on, both masses positive with
@@ -419,8 +418,8 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
     const long ucol = (long)(J < nj + 2 * NG ? J : nj + 2 * NG - 1) * sj;
     const bool store_lane = lane >= HALO && lane < WAVE - HALO && J < nj + NG;
     const int jz = J - NG;
-    const double yc = P.yl + (jz + 0.5) * P.dy;
-    const double yf = P.yl + (double)jz * P.dy;
+    const double yc = mesh_coord(P.yl, jz + 0.5, P.dy);
+    const double yf = mesh_coord(P.yl, (double)jz, P.dy);
 
     const int I0 = NG + P.i_begin + chunk * P.rows_per_chunk;
     int I1 = I0 + P.rows_per_chunk;
@@ -474,13 +473,27 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
             pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = row_in[q];
         }
     };
+    // Row table (see iso_stage_kernel): the x-dependent, lane-independent quantities of 64 rows in LDS, filled by
+    // the lanes once per 60 rows, read by broadcast in the march.
+    __shared__ double row_table[4][WAVE][ROW_ENTRY];
+    double (*const tab)[ROW_ENTRY] = row_table[threadIdx.x >> 6];
+    auto fill_rows = [&](int T) { // entries of rows T-2 ... T+61, slot = row & 63
+        const int rho = T - 2 + lane;
+        const double xfr = mesh_coord(P.xl, (double)(rho - NG), P.dx);  // lower x-face of row rho
+        const double xcr = mesh_coord(P.xl, (rho - NG) + 0.5, P.dx);    // its centre
+        double *e = tab[rho & (WAVE - 1)];
+        e[0] = xfr - P.m[0].x; e[1] = xfr - P.m[1].x;
+        e[2] = xcr - P.m[0].x; e[3] = xcr - P.m[1].x;
+        e[4] = xcr;
+    };
     // Bring-up: all that row I0-1 has to provide is the lower side of the x-face between it and row I0 (see
     // sf_iso.hpp: a whole iteration of the march used to be spent on it).
     {
         const double *src = row(I0 + 1);
         pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
         double gx[4], sxx, syy, sxy;
-        gam_row_state<FULL>(P, pa, pb, pc, gyb, visc, hvar, hidx, hidy, P.xl + ((I0 - 1 - NG) + 0.5) * P.dx, oyc0, oyc1,
+        const double xc0 = mesh_coord(P.xl, (I0 - 1 - NG) + 0.5, P.dx); // (the row table's operations: same bits)
+        gam_row_state<FULL>(P, pa, pb, pc, gyb, visc, hvar, hidx, hidy, xc0 - P.m[0].x, xc0 - P.m[1].x, oyc0, oyc1,
                             gx, sxx, syy, sxy, qha, csa, nua);
 #pragma unroll
         for (int q = 0; q < 4; ++q) pmx[q] = __builtin_fma(quarter, gx[q], pb[q]);
@@ -488,8 +501,15 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
         enter(pn);
     }
 
+    int refill = I0 + 1; // the iteration that next renews the row table
 #pragma unroll 1
     for (int r = I0 + 1; r <= I1 + 1; ++r) {
+        if (r == refill) { fill_rows(r); refill += ROW_TABLE_SPAN; }
+        // (read here, with the global requests, well before their first use)
+        const double *ebp = tab[(r - 1) & (WAVE - 1)]; // row r-1: faces
+        const double *eap = tab[(r - 2) & (WAVE - 1)]; // row r-2: the update
+        const double eb[4] = {ebp[0], ebp[1], ebp[2], ebp[3]};
+        const double ea[5] = {0.0, 0.0, eap[2], eap[3], eap[4]};
         const bool upd = r - 2 >= I0; // the first iteration only brings the pipeline up
         if (UN && upd) {
             // u^n of the row updated at the bottom of this iteration: the whole iteration covers its latency
@@ -497,18 +517,36 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
             un[0] = us[0]; un[1] = us[1]; un[2] = us[2]; un[3] = us[3];
         }
         { // (the last iteration's request is never consumed: a clamped, valid row; saves a branch)
+#if defined(SFHIP_DIAG_SAME_ROW)  // diagnosis builds only: every request hits the cache
+            const double *src = row(I0 + (r & 1));
+#else
             const double *src = row(r + 1);
+#endif
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
         }
         __builtin_amdgcn_sched_barrier(0); // keep the requests first
+#if defined(SFHIP_DIAG_NO_COMPUTE)  // diagnosis builds only (WRONG results): the march's memory traffic without its arithmetic
+        {
+            double o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] = pa[q] + (UN ? un[q] : 0.0);
+                pa[q] = pb[q]; pb[q] = pc[q]; pc[q] = pn[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (upd && store_lane) {
+                const long c = (long)(r - 2) * si + (long)J * sj;
+                pwr[c] = o[0]; pwr[c + 1] = o[1]; pwr[c + 2] = o[2]; pwr[c + 3] = o[3];
+            }
+            continue;
+        }
+#endif
 
         {
-            const double xf = P.xl + (double)(r - 1 - NG) * P.dx;
-            const double xcb = P.xl + ((r - 1 - NG) + 0.5) * P.dx;
             // row r-1: slopes, strain, sqrt(p/sigma), sound speed, nu / 2 at the zone centre (all viscosities below
             // are HALF the reference's nu, cbdgam_2d.c:639-648: see gam_row_state)
             double gxb[4], sxx, syy, sxy, qhb, csb, nub;
-            gam_row_state<FULL>(P, pa, pb, pc, gyb, visc, hvar, hidx, hidy, xcb, oyc0, oyc1, gxb, sxx, syy, sxy, qhb, csb, nub);
+            gam_row_state<FULL>(P, pa, pb, pc, gyb, visc, hvar, hidx, hidy, eb[2], eb[3], oyc0, oyc1, gxb, sxx, syy, sxy, qhb, csb, nub);
 
             // Both faces are evaluated in every iteration (the first one's x-face and the last one's y-face go
             // unused), so that the fluxes are plain locals and `acc` is written unconditionally.
@@ -520,17 +558,18 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                 for (int q = 0; q < 4; ++q) ppx[q] = pb[q] - quarter * gxb[q];
                 gam_hlle2_fast<0>(pmx, ppx, csa, csb, P.inv_gm1, FR, FL);
                 if (visc) {
-                    double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, xf, oyc0, oyc1) : 1.0;
+                    double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, eb[0], eb[1], oyc0, oyc1) : 1.0;
                     double nufL = P.half_alpha * (hvar ? qha * iof : 1.0) * csa; // cbdgam_2d.c:639,645
                     double nufR = P.half_alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:640,646
                     double txa = pa[0] * sxxa, tya = pa[0] * sxya, txb = pb[0] * sxx, tyb = pb[0] * sxy;
                     double exa = txa * pa[1] + tya * pa[2], exb = txb * pb[1] + tyb * pb[2];
-                    FR[1] -= nufL * txa + nub * txb;
-                    FR[2] -= nufL * tya + nub * tyb;
-                    FR[3] -= nufL * exa + nub * exb;
-                    FL[1] -= nua * txa + nufR * txb;
-                    FL[2] -= nua * tya + nufR * tyb;
-                    FL[3] -= nua * exa + nufR * exb;
+                    // (two fused multiply-adds per component; as `F -= a x + b y` it is a product, an FMA and a subtraction)
+                    FR[1] = __builtin_fma(-nub, txb, __builtin_fma(-nufL, txa, FR[1]));
+                    FR[2] = __builtin_fma(-nub, tyb, __builtin_fma(-nufL, tya, FR[2]));
+                    FR[3] = __builtin_fma(-nub, exb, __builtin_fma(-nufL, exa, FR[3]));
+                    FL[1] = __builtin_fma(-nufR, txb, __builtin_fma(-nua, txa, FL[1]));
+                    FL[2] = __builtin_fma(-nufR, tyb, __builtin_fma(-nua, tya, FL[2]));
+                    FL[3] = __builtin_fma(-nufR, exb, __builtin_fma(-nua, exa, FL[3]));
                 }
             }
             // row r-2 is complete with its upper face (as that row sees it): -(dF/dx + dG/dy) dt
@@ -544,23 +583,23 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                     pmy[q] = from_lane_below(pb[q] + quarter * gyb[q]);
                     ppy[q] = pb[q] - quarter * gyb[q];
                 }
-                double csl = from_lane_below(csb);
+                const double qhl = from_lane_below(qhb);
+                const double csl = qhl * P.sqrt_gamma; // the neighbour's own product, bit for bit (gam_row_state)
                 gam_hlle2_fast<1>(pmy, ppy, csl, csb, P.inv_gm1, GR, GL);
                 if (visc) {
                     double txb = pb[0] * sxy, tyb = pb[0] * syy;          // rho tau^y_x, rho tau^y_y of this zone
                     double exb = txb * pb[1] + tyb * pb[2];
                     double txl = from_lane_below(txb), tyl = from_lane_below(tyb), exl = from_lane_below(exb);
-                    double qhl = from_lane_below(qhb);
                     double nul = from_lane_below(nub);
-                    double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, xcb, oyf0, oyf1) : 1.0;
+                    double iof = hvar ? gam_inv_omega_fast<FULL>(P.m, eb[2], eb[3], oyf0, oyf1) : 1.0;
                     double nufL = P.half_alpha * (hvar ? qhl * iof : 1.0) * csl; // cbdgam_2d.c:641,647
                     double nufR = P.half_alpha * (hvar ? qhb * iof : 1.0) * csb; // cbdgam_2d.c:642,648
-                    GR[1] -= nufL * txl + nub * txb;
-                    GR[2] -= nufL * tyl + nub * tyb;
-                    GR[3] -= nufL * exl + nub * exb;
-                    GL[1] -= nul * txl + nufR * txb;
-                    GL[2] -= nul * tyl + nufR * tyb;
-                    GL[3] -= nul * exl + nufR * exb;
+                    GR[1] = __builtin_fma(-nub, txb, __builtin_fma(-nufL, txl, GR[1]));
+                    GR[2] = __builtin_fma(-nub, tyb, __builtin_fma(-nufL, tyl, GR[2]));
+                    GR[3] = __builtin_fma(-nub, exb, __builtin_fma(-nufL, exl, GR[3]));
+                    GL[1] = __builtin_fma(-nufR, txb, __builtin_fma(-nul, txl, GL[1]));
+                    GL[2] = __builtin_fma(-nufR, tyb, __builtin_fma(-nul, tyl, GL[2]));
+                    GL[3] = __builtin_fma(-nufR, exb, __builtin_fma(-nul, exl, GL[3]));
                 }
                 // upper face of this zone is the lower face of lane j+1, seen from below
 #pragma unroll
@@ -568,7 +607,7 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
             }
             if (upd) {
                 // update row r-2 (cbdgam_2d.c:669-681)
-                const double xc = P.xl + ((r - 2 - NG) + 0.5) * P.dx;
+                const double xc = ea[4];
                 const double rinva = fast_rcp(pa[0]);
                 const double eps = pa[3] * rinva * P.inv_gm1;
                 double u[4];
@@ -576,10 +615,10 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                 u[3] = pa[3] * P.inv_gm1 + 0.5 * pa[0] * (pa[1] * pa[1] + pa[2] * pa[2]);
                 // disk_height at the zone centre is only consumed by non-constant softening
                 double hcc = 1.0;
-                if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast<FULL>(P.m, xc, oyc0, oyc1);
+                if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast<FULL>(P.m, ea[2], ea[3], oyc0, oyc1);
                 gam_buffer_fast<FULL>(P, xc, yc, yc2, u);
-                gam_mass_source_fast<FULL>(P.m[0], P.sink_near2[0], &Pk->m[0], xc, dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
-                gam_mass_source_fast<FULL>(P.m[1], P.sink_near2[1], &Pk->m[1], xc, dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_mass_source_fast<FULL>(P.m[0], P.sink_near2[0], &Pk->m[0], ea[2], dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
+                gam_mass_source_fast<FULL>(P.m[1], P.sink_near2[1], &Pk->m[1], ea[3], dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
                 gam_cooling_fast(P, pa, eps, rinva, u);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) u[q] += tot[q];
@@ -601,7 +640,7 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                         // same filter as the isothermal kernel: a ~1-ulp estimate decides which zones
                         // get the IEEE evaluation, so the reduced maximum is bit-exact
                         double pre = pres * fast_rcp(rho) * gamma;
-                        double cse = sqrt_from_rsqrt(pre, fast_rsqrt(pre));
+                        double cse = fast_sqrt(pre);
                         if (!((max2(fabs(vx), fabs(vy)) + cse) * (1.0 + 1e-9) < athr)) { // unordered passes
                             amax = max_nan(amax, gam_exact_speed(vx, vy, pres, rho, gamma));
                             athr = max2(athr, amax);
@@ -614,7 +653,11 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
             sxxa = sxx; sxya = sxy; csa = csb; qha = qhb; nua = nub;
             enter(pn); // row r+1 enters the window
             __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
+#if defined(SFHIP_DIAG_NO_STORE)  // diagnosis builds only: what the stores cost
+            if (upd && store_lane && out[0] < -1e300) {
+#else
             if (upd && store_lane) {
+#endif
                 const long c = (long)(r - 2) * si + (long)J * sj;
                 pwr[c] = out[0]; pwr[c + 1] = out[1]; pwr[c + 2] = out[2]; pwr[c + 3] = out[3];
             }

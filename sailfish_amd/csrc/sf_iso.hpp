@@ -19,9 +19,6 @@
 
 namespace sf {
 
-constexpr int ROW_ENTRY = 6;        // doubles per entry of a marching wave's row table (5 used; 48-byte entries)
-constexpr int ROW_TABLE_SPAN = 60;  // rows between two refills of the 64-entry table (an iteration looks back 2 rows)
-
 struct IsoParams {
     int ni, nj;                 // interior zones of the patch
     double xl, yl, dx, dy;      // patch origin and spacing (dx = (xr-xl)/ni on the host, cbdiso_2d.c:440)
