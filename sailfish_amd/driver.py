@@ -187,30 +187,76 @@ def write_checkpoint(number, outdir, state):
     return filename
 
 
+class Recurrence(NamedTuple):
+    """An event's recurrence rule as a checkpoint's ``driver.events`` holds it (reference: event.py:11-23; kind 0
+    linear, 1 log).  Data only: the event loop is the reference driver's, out of scope here."""
+
+    kind: int = None
+    interval: float = None
+
+
+class RecurringEvent(NamedTuple):
+    """An event's state as a checkpoint's ``event_states`` holds it (reference: event.py:51-61)."""
+
+    last_time: float = None
+    number: int = 0
+
+
+class _ForeignRecord(tuple):
+    """Stand-in for a ``sailfish.*`` class this package has no counterpart of: keeps the constructor arguments (and
+    whatever state the pickle sets).  A class, because NamedTuples pickle with NEWOBJ, which needs a type."""
+
+    def __new__(cls, *args, **kwargs):
+        self = super().__new__(cls, args)
+        self.__dict__.update(kwargs)
+        return self
+
+
+# What a checkpoint may name.  Nothing else is resolved: a checkpoint is data, and unpickling must not be a way to
+# reach os.system or eval through a GLOBAL opcode (newest_chkpt_in_directory opens every candidate in a directory).
+_CHECKPOINT_MODULES = ("sailfish_amd.mesh", "sailfish_amd.driver", "sailfish_amd.physics.circumbinary",
+                       "sailfish_amd.physics.kepler", "sailfish_amd.setups")
+_CHECKPOINT_GLOBALS = {
+    ("builtins", n) for n in ("complex", "set", "frozenset", "dict", "list", "tuple", "bytearray", "bytes", "float", "int",
+                              "bool", "slice", "range", "str")
+} | {("_codecs", "encode"), ("copyreg", "_reconstructor"), ("builtins", "object")  # (how protocols 0-2 spell bytes and plain objects)
+} | {("collections", "OrderedDict"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float64"), ("numpy", "int64"),
+     ("numpy", "bool_"), ("numpy", "complex128")} | {
+    (m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("_reconstruct", "scalar")
+} | {(m, "_frombuffer") for m in ("numpy.core.numeric", "numpy._core.numeric")}
+
+
 class _CheckpointUnpickler(pickle.Unpickler):
     """
-    Checkpoints pickle application objects (mesh, driver arguments, point masses, enums).  One written by the
-    reference names them ``sailfish.<module>.<Class>``; the same classes live here under ``sailfish_amd``, with
-    the same fields, so such names are resolved to ours -- a reference checkpoint restarts here without the
-    reference installed.  (``Recurrence`` event descriptions are control plane: kept as plain tuples.)
+    Checkpoints pickle application objects (mesh, driver arguments, point masses, enums, event tuples) and numpy
+    arrays.  One written by the reference names its classes ``sailfish.<module>.<Class>``; the same classes live here
+    under ``sailfish_amd`` with the same fields, so such names are resolved to ours -- a reference checkpoint restarts
+    here without the reference installed; a ``sailfish.*`` class without a counterpart becomes a ``_ForeignRecord``.
+    Every other global must be on the allow-list above (classes DEFINED in this package's data modules, numpy's array
+    reconstructors, a few builtins); anything else is an ``UnpicklingError``.
     """
 
     def find_class(self, module, name):
-        if module == "sailfish" or module.startswith("sailfish."):
-            local = "sailfish_amd" + module[len("sailfish"):]
-            if name in ("Recurrence", "RecurringEvent"):
-                return _plain_record
-            if local.endswith(".driver") and name in ("DriverArgs", "DriverState"):
-                return globals()[name]
+        foreign = module == "sailfish" or module.startswith("sailfish.")
+        local = "sailfish_amd" + module[len("sailfish"):] if foreign else module
+        if local == "sailfish_amd.event" and name in ("Recurrence", "RecurringEvent"):
+            return globals()[name]
+        if local in _CHECKPOINT_MODULES and "." not in name:
+            import importlib
+
             try:
-                return super().find_class(local, name)
+                obj = getattr(importlib.import_module(local), name)
             except (ImportError, AttributeError):
-                return _plain_record
-        return super().find_class(module, name)
-
-
-def _plain_record(*args, **kwargs):
-    return dict(args=args, **kwargs)
+                obj = None
+            # classes defined in that module only: not what the module happens to have imported
+            if isinstance(obj, type) and obj.__module__ == local:
+                return obj
+        if foreign:
+            return _ForeignRecord
+        if (module, name) in _CHECKPOINT_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which no checkpoint of this package or of the "
+                                     "reference holds: refusing to resolve it")
 
 
 def load_checkpoint(chkpt_file):

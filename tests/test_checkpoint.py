@@ -109,6 +109,64 @@ def test_reference_written_checkpoint_loads_without_the_reference(tmp_path):
     assert np.array_equal(again.solver.solution, state.solver.solution)
 
 
+def test_reference_checkpoint_with_events_and_event_states(tmp_path):
+    """What the reference's checkpoint EVENT writes: driver.events holds Recurrence rules and event_states holds
+    RecurringEvent tuples (event.py:11, 51) -- NamedTuples, pickled with NEWOBJ at the default protocol, so whatever
+    stands in for them must be a type.  A sailfish.* class without a counterpart here loads as a record of its
+    constructor arguments."""
+    import collections
+    import sys
+    import types
+
+    from sailfish_amd.driver import Recurrence, RecurringEvent
+
+    # the reference's two tuples as its pickles name them: a throw-away module `sailfish.event` (and an unknown class)
+    fake = types.ModuleType("sailfish.event")
+    for cls_name, fields in (("Recurrence", "kind interval"), ("RecurringEvent", "last_time number"), ("Mystery", "a b")):
+        cls = collections.namedtuple(cls_name, fields)
+        cls.__module__ = "sailfish.event"
+        setattr(fake, cls_name, cls)
+    sys.modules["sailfish.event"] = fake
+    sys.modules.setdefault("sailfish", types.ModuleType("sailfish"))
+    try:
+        payload = dict(event_states={"checkpoint": fake.RecurringEvent(3.0, 4), "timeseries": fake.RecurringEvent(None, 0)},
+                       events={"checkpoint": fake.Recurrence(0, 1.0), "timeseries": fake.Recurrence(1, 0.01)},
+                       extra=fake.Mystery(1, "two"), solution=np.arange(6.0).reshape(2, 3), z=complex(1, 2))
+        path = tmp_path / "chkpt.0003.pk"
+        path.write_bytes(pickle.dumps(payload))  # default protocol: NEWOBJ for the tuples
+    finally:
+        del sys.modules["sailfish.event"]
+        if not hasattr(sys.modules.get("sailfish"), "__path__"):
+            sys.modules.pop("sailfish", None)
+    chkpt = load_checkpoint(str(path))
+    assert chkpt["event_states"]["checkpoint"] == RecurringEvent(3.0, 4)
+    assert isinstance(chkpt["event_states"]["checkpoint"], RecurringEvent) and chkpt["event_states"]["checkpoint"].number == 4
+    assert chkpt["events"]["timeseries"] == Recurrence(1, 0.01) and isinstance(chkpt["events"]["checkpoint"], Recurrence)
+    assert tuple(chkpt["extra"]) == (1, "two")
+    assert np.array_equal(chkpt["solution"], np.arange(6.0).reshape(2, 3)) and chkpt["z"] == complex(1, 2)
+
+
+def test_checkpoint_loader_resolves_nothing_but_checkpoint_classes(tmp_path):
+    """The loader is for data: a pickle that names anything outside the allow-list (os.system, builtins.eval, a
+    module attribute that is not a class of this package's data modules) is refused, not executed."""
+    evil = [
+        b"cos\nsystem\n(S'echo pwned'\ntR.",
+        b"cbuiltins\neval\n(S'1+1'\ntR.",
+        b"csailfish_amd.driver\nos\n.",            # what a module imported is not a checkpoint class
+        b"csailfish_amd.driver\nload_checkpoint\n.",  # nor are its functions
+        b"csubprocess\nPopen\n.",
+    ]
+    for k, blob in enumerate(evil):
+        path = tmp_path / f"chkpt.{k:04d}.pk"
+        path.write_bytes(blob)
+        with pytest.raises(pickle.UnpicklingError):
+            load_checkpoint(str(path))
+    from sailfish_amd.driver import newest_chkpt_in_directory
+
+    with pytest.raises(ValueError):
+        newest_chkpt_in_directory(str(tmp_path))  # none of them is usable, and none ran
+
+
 def test_write_checkpoint_argument_checks(tmp_path):
     from oracle_backend import OracleBackend
 
