@@ -711,6 +711,18 @@ int sfhip_step_group_rk2(int group, double *const *state, double *const *other, 
                          double wavespeed_floor, double floor_fraction, double host_seq, double *result3);
 int sfhip_step_group_timing(int group, double *out5);
 
+/* Host only, no GPU involved: initial data of the GAMMA-LAW circumbinary disk (sailfish/setups/circumbinary_disk.py:
+ * 94-108 through initial_condition(), sailfish/solvers/cbdgam_2d.py:30-43 -- the Python double loop over every zone),
+ * zones [i0, i0 + ni) x [0, nj) of the mesh with origin (x0, y0) and spacing (dx, dy), into the HOST array
+ * out_host[ni][nj][4] (no guards).  The formulas call pow and exp, which no device library reproduces bit for bit, so
+ * this one stays on the host: the same libm calls the interpreter makes per point (x ** y is pow(x, y), math.exp is
+ * exp), in the same order, spread over `threads` host threads (<= 0: as many as the process may use, at most 64) --
+ * bit-identical to the reference's loop on the same machine, at 67 M zones (8192^2) in under a second instead of
+ * minutes.  exponent_sigma / exponent_pressure are -3/5 and -3/2 as the caller's own divisions give them. */
+int sfhip_host_gamma_law_disk_primitive(int ni, int nj, double x0, double y0, double dx, double dy, int i0, double softening2,
+                                        double sigma, double pressure, double exponent_sigma, double exponent_pressure,
+                                        int threads, double *out_host);
+
 /* Host only, no GPU involved: the orbital state (mass, x, y, vx, vy of body 1, then body 2) into 10 host doubles. */
 int sfhip_kepler_orbital_state(double semimajor_axis, double total_mass, double mass_ratio, double eccentricity,
                                double time_since_periapse, double *out10_host);

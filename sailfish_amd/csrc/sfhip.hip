@@ -18,6 +18,9 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+#include <sched.h>
+#include <thread>
+#include <vector>
 
 #include "sf_dg.hpp"
 #include "sf_gam.hpp"
@@ -428,6 +431,49 @@ int sfhip_circumbinary_disk_primitive(int ni, int nj, double x0, double y0, doub
     hipLaunchKernelGGL(sf::disk_primitive_kernel, grid, block, 0, t_stream, ni, nj, i0, x0, y0, dx, dy, softening2,
                        sigma, primitive);
     return check_launch("sfhip_circumbinary_disk_primitive");
+}
+
+// Initial data of the gamma-law circumbinary disk on the HOST (include/sfhip.h): CircumbinaryDisk.primitive's
+// operations, circumbinary_disk.py:82-108, with the libm calls the interpreter makes (host code is compiled with
+// contraction off as well), rows spread over threads.
+int sfhip_host_gamma_law_disk_primitive(int ni, int nj, double x0, double y0, double dx, double dy, int i0, double softening2,
+                                        double sigma, double pressure, double exponent_sigma, double exponent_pressure,
+                                        int threads, double *out)
+{
+    if (ni < 1 || nj < 1 || i0 < 0 || !out) return fail(-1, "sfhip_host_gamma_law_disk_primitive: bad arguments");
+    if (threads <= 0) {
+        cpu_set_t set;
+        threads = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 1;
+        const int cap = env_int("OMP_NUM_THREADS", 64);
+        if (threads > cap) threads = cap;
+        if (threads > 64) threads = 64;
+    }
+    if (threads > ni) threads = ni;
+    if (threads < 1) threads = 1;
+    auto rows = [=](int a, int b) {
+        for (int i = a; i < b; ++i) {
+            const double x = x0 + ((double)(i0 + i) + 0.5) * dx; // mesh.cell_coordinates
+            for (int j = 0; j < nj; ++j) {
+                const double y = y0 + ((double)j + 0.5) * dy;
+                const double r = sqrt(x * x + y * y);
+                const double rs = sqrt(x * x + y * y + softening2);
+                const double rc = r > 1e-12 ? r : 1e-12;                       // max(r, 1e-12)
+                const double phx = -y / rc, phy = x / rc;
+                const double cavity = 0.0001 + 0.9999 * exp(-pow(1.0 / rs, 30.0));
+                double *p = out + ((long)i * nj + j) * 4;
+                p[0] = sigma * pow(rs, exponent_sigma) * cavity;
+                p[1] = sqrt(1.0 / rs) * phx;
+                p[2] = sqrt(1.0 / rs) * phy;
+                p[3] = pressure * pow(rs, exponent_pressure) * cavity;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t)
+        pool.emplace_back(rows, (int)((long)ni * t / threads), (int)((long)ni * (t + 1) / threads));
+    rows(0, (int)((long)ni / threads));
+    for (auto &th : pool) th.join();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

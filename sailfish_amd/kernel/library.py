@@ -102,9 +102,16 @@ _CTYPES = {
 class Library:
     """
     Loads ``libsfhip.so`` and exposes its kernels with the reference's calling
-    convention.  `code`, `name` and `define_macros` are accepted for signature
-    compatibility with ``sailfish.kernel.library.Library`` and ignored: there is
-    no JIT step in this mode.
+    convention (``sailfish.kernel.library.Library``, library.py:165-185).  Nothing is
+    compiled in this mode, but `code` -- the kernel source text a reference solver reads
+    from the ``.c`` file beside it and hands over -- still says what the caller is about
+    to call: every ``PUBLIC void`` kernel it declares must exist in the library with the
+    same argument types and names in the same order, or construction fails with
+    ``KernelError`` (a binding gets that check at run time, without the reference's
+    sources having to be anywhere near the library's tests).  `define_macros`: the
+    srhd_2d kernels' ``PLM_THETA`` / ``MACH_CEILING`` are settings of the prebuilt
+    library (``sfhip_srhd_2d_set_macros``) and are applied; any other macro cannot be
+    honoured by prebuilt code and is refused.  `name` is accepted and unused.
     """
 
     def __init__(self, code=None, mode="hip", name="sfhip", debug=True, define_macros=None, path=None):
@@ -141,6 +148,39 @@ class Library:
         self.module.sfhip_selftest_lane_shift.argtypes = [ctypes.c_void_p] * 3
         self._torch = torch
         logger.info(f"loaded {self.path} with {len(self.api)} kernels")
+        if code is not None:
+            self.check_code(code)
+        if define_macros:
+            self.apply_macros(dict(define_macros))
+
+    def check_code(self, code):
+        """The ``PUBLIC void`` kernels of `code` against the library's: names, argument types, names and order."""
+        from .parse_api import parse_reference_api, signature_mismatch
+
+        try:
+            declared = parse_reference_api(code)
+        except ValueError as exc:
+            raise KernelError(f"cannot read the kernel declarations of the code handed to Library: {exc}")
+        for name, sym in declared.items():
+            if name not in self.api:
+                raise KernelError(f"the code declares kernel {name}, which {self.path} does not provide")
+            problem = signature_mismatch(sym, self.api[name])
+            if problem:
+                raise KernelError(f"the code handed to Library does not match {self.path}: {problem}")
+        self.declared = sorted(declared)
+
+    def apply_macros(self, macros):
+        """PLM_THETA / MACH_CEILING of the srhd_2d kernels (srhd_2d.py:232-240); nothing else can change prebuilt code."""
+        unknown = sorted(set(macros) - {"PLM_THETA", "MACH_CEILING"})
+        if unknown:
+            raise KernelError(f"libsfhip.so is prebuilt: the macros {unknown} cannot be applied to it")
+        kernel = self._kernels.get("sfhip_srhd_2d_set_macros")
+        if kernel is None:
+            raise KernelError("this library has no srhd_2d kernels to apply PLM_THETA / MACH_CEILING to")
+        # (what the macros default to in the reference's source, srhd_2d.c, when only one of them is given)
+        status = kernel.cfunc(1, float(macros.get("PLM_THETA", 1.5)), float(macros.get("MACH_CEILING", 1e6)))
+        if status != 0:
+            raise KernelError(f"sfhip_srhd_2d_set_macros failed ({status}): {self.last_error()}")
 
     @property
     def xp(self):

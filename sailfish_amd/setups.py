@@ -153,20 +153,50 @@ class CircumbinaryDisk(Setup):
 
     def primitive_array(self, t, mesh, i0=0, i1=None, num_fields=None):
         """
-        Rows [i0, i1) of the initial data, vectorised.  The isothermal branch uses
+        Rows [i0, i1) of the initial data without the interpreter loop.  The isothermal branch uses
         only + * / sqrt max, all correctly rounded in numpy, so it is bit-identical
         to the per-point loop (checked in tests).  The gamma-law branch calls
-        pow/exp, where numpy's vector kernels may differ from libm in the last
-        place; small meshes therefore go through the exact per-point loop.
+        pow/exp, where numpy's vector kernels differ from libm in the last
+        place at ~5 % of the zones: those rows come from libsfhip.so's host routine
+        (the per-point formulas with the interpreter's own libm calls, threaded:
+        bit-identical, tested at 8192^2); without the library small meshes go through
+        the per-point loop and large ones through numpy.
         """
         i1 = mesh.ni if i1 is None else i1
-        if self.is_gamma_law and (i1 - i0) * mesh.nj <= (1 << 18):
-            return Setup.primitive_array(self, t, mesh, i0, i1, 4)
+        if self.is_gamma_law:
+            exact = self._gamma_law_rows_native(mesh, i0, i1)
+            if exact is not None:
+                return exact
+            if (i1 - i0) * mesh.nj <= (1 << 18):
+                return Setup.primitive_array(self, t, mesh, i0, i1, 4)
         i = np.arange(i0, i1, dtype=np.float64)[:, None]
         j = np.arange(mesh.nj, dtype=np.float64)[None, :]
         x = mesh.x0 + (i + 0.5) * mesh.dx
         y = mesh.y0 + (j + 0.5) * mesh.dy
         return self._primitive_vectorised(x, y, (i1 - i0, mesh.nj))
+
+    def _gamma_law_rows_native(self, mesh, i0, i1):
+        """Rows [i0, i1) of the gamma-law disk from libsfhip.so's HOST routine (sfhip_host_gamma_law_disk_primitive:
+        the per-point formulas with the libm calls the interpreter makes, threaded; bit-identical to ``primitive``),
+        or None where the library is not available (CPU-only checks of the host logic: the slower paths below)."""
+        import ctypes
+
+        try:
+            from .kernel.library import Library
+
+            fn = Library(mode="hip").module.sfhip_host_gamma_law_disk_primitive
+        except Exception:
+            return None
+        d, i = ctypes.c_double, ctypes.c_int
+        fn.argtypes = [i, i, d, d, d, d, i, d, d, d, d, d, i, ctypes.POINTER(d)]
+        fn.restype = i
+        out = np.empty([i1 - i0, mesh.nj, 4])
+        status = fn(i1 - i0, mesh.nj, mesh.x0, mesh.y0, mesh.dx, mesh.dy, i0,
+                    self.softening_length * self.softening_length, float(self.initial_sigma), float(self.initial_pressure),
+                    -3.0 / 5.0, -3.0 / 2.0, 0, out.ctypes.data_as(ctypes.POINTER(d)))
+        if status != 0:
+            raise SetupError("sfhip_host_gamma_law_disk_primitive failed")
+        return out
 
     def primitive_points(self, t, x, y, num_fields=None):
         if self.is_gamma_law and x.size <= (1 << 18):
@@ -176,7 +206,8 @@ class CircumbinaryDisk(Setup):
     @property
     def has_device_primitive(self):
         """The isothermal disk's initial data can be made on the device bit for bit (only + * / sqrt max); the
-        gamma-law disk's pow/exp cannot, so that branch stays on the host."""
+        gamma-law disk's pow/exp cannot (glibc's are not correctly rounded and no device library repeats their
+        last-place choices), so that branch is made by libsfhip.so's threaded host routine and copied."""
         return self.is_isothermal
 
     def device_primitive(self, lib, t, mesh, i0, i1, out):

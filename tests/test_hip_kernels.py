@@ -312,3 +312,40 @@ def test_boundary_errors(hip_lib):
         c = cases.iso_case()
         d = dev(c["prim"])
         hip_lib.cbdiso_2d_advance_rk[c["shape"]](*cases.iso_advance_args(c, dev(c["cons"]), d, d))
+
+
+@pytest.mark.parametrize("solver", ["iso", "gam"])
+def test_one_nan_zone_after_one_stage(hip_lib, orc, solver):
+    """What a NaN in ONE zone of the input does to one advance_rk stage, reference arithmetic (oracle) against the
+    kernels -- the documented difference, pinned.  Nothing outside the stencil's reach (|di| + |dj| <= 2) is touched
+    in either, and there the two agree to the usual bar.  cbdgam_2d: the kernels' slopes drop a NaN neighbour
+    (v_min_f64) where the reference's `?:` minmod passes some of them on, so the device's NaN zones are exactly the
+    zone and its four face neighbours, and the reference's set contains them (it reaches two zones in -i and -j).
+    cbdiso_2d: no NaN survives the recovery in either (cbdiso_2d.c:268-283 turns it into floor density at ceiling
+    velocity): the seeded zone comes out at the floor and the ceiling in both, which is what kills dt."""
+    ni, nj, i0, j0 = 24, 30, 12, 15
+    make, args, name, nq = ((cases.iso_case, cases.iso_advance_args, "cbdiso_2d_advance_rk", 3) if solver == "iso" else
+                            (cases.gam_case, cases.gam_advance_args, "cbdgam_2d_advance_rk", 4))
+    di, dj = np.meshgrid(np.arange(ni) - i0, np.arange(nj) - j0, indexing="ij")
+    reach = np.abs(di) + np.abs(dj)
+    for field in range(nq):
+        c = make(seed=5, ni=ni, nj=nj)
+        prim = c["prim"].copy()
+        prim[2 + i0, 2 + j0, field] = np.nan
+        expect = np.zeros_like(prim)
+        orc.call(name, c["shape"], *args(c, c["cons"], prim, expect))
+        wr = dev(np.zeros_like(prim))
+        getattr(hip_lib, name)[c["shape"]](*args(c, dev(c["cons"]), dev(prim), wr))
+        got, expect = host(wr)[2:-2, 2:-2], expect[2:-2, 2:-2]
+        far = reach > 2
+        assert np.isfinite(got[far]).all() and np.isfinite(expect[far]).all()
+        scale = np.abs(expect[far]).max()
+        assert np.abs(got[far] - expect[far]).max() <= ADVANCE_TOL * scale
+        nan_hip, nan_ref = np.isnan(got).any(-1), np.isnan(expect).any(-1)
+        if solver == "gam":
+            assert np.array_equal(nan_hip, reach <= 1), field   # the zone and its four face neighbours
+            assert nan_ref[nan_hip].all() and not nan_ref[far].any() and nan_ref.sum() >= nan_hip.sum()
+        else:
+            assert not nan_hip.any() and not nan_ref.any()
+            for a in (got, expect):
+                assert a[i0, j0, 0] == 1e-12 and abs(a[i0, j0, 1]) == 1e12 and abs(a[i0, j0, 2]) == 1e12

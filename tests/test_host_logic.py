@@ -259,3 +259,68 @@ def test_reductions_reject_what_the_reference_cannot_evaluate():
                         distributed=False)
         with pytest.raises(ValueError):
             s.reductions()
+
+
+MATCHING_CODE = """
+#define NCONS 3
+static double helper(double x) { return x; }
+
+PUBLIC void cbdiso_2d_primitive_to_conserved(
+    int ni,
+    int nj,
+    double *primitive, // :: $.shape == (ni + 4, nj + 4, 3)
+    double *conserved) // :: $.shape == (ni + 4, nj + 4, 3)
+{
+    int ng = 2;
+}
+
+PUBLIC void cbdgam_2d_wavespeed(int ni, int nj,
+    double *primitive, double *wavespeed,
+    double gamma_law_index)
+{
+}
+"""
+
+
+def test_library_checks_the_code_it_is_handed():
+    """``Library(code, mode=...)`` is how a reference solver makes its kernel library (library.py:165-185,
+    cbdiso_2d.py:303-305).  Nothing is compiled in the hip mode, but the ``PUBLIC void`` declarations of the code are
+    checked against the library: same kernels, same argument types and names, same order -- a binding learns at
+    construction, not from a wrong result, that the text it hands over is not what the library implements."""
+    from sailfish_amd.kernel.library import KernelError, Library
+    from sailfish_amd.kernel.parse_api import parse_reference_api
+
+    api = parse_reference_api(MATCHING_CODE)
+    assert sorted(api) == ["cbdgam_2d_wavespeed", "cbdiso_2d_primitive_to_conserved"]
+    assert [a.name for a in api["cbdgam_2d_wavespeed"].args] == ["ni", "nj", "primitive", "wavespeed", "gamma_law_index"]
+    assert api["cbdiso_2d_primitive_to_conserved"].args[2].constraint == "$.shape == (ni + 4, nj + 4, 3)"
+    assert api["cbdiso_2d_primitive_to_conserved"].rank == 2
+    lib = Library(MATCHING_CODE, mode="hip", debug=False)
+    assert lib.declared == sorted(api)
+    for wrong, what in (
+        (MATCHING_CODE.replace("double *conserved)", "double *conserved,\n    double extra)"), "arguments"),
+        (MATCHING_CODE.replace("double gamma_law_index", "int gamma_law_index"), "argument 4"),
+        (MATCHING_CODE.replace("double *primitive, double *wavespeed", "double *wavespeed, double *primitive"), "argument 2"),
+        (MATCHING_CODE.replace("cbdgam_2d_wavespeed", "cbdgam_2d_no_such_kernel"), "does not provide"),
+        (MATCHING_CODE.replace("int nj,\n    double *primitive, //", "int nj,\n    float *primitive, //"), "cannot read"),
+    ):
+        with pytest.raises(KernelError, match=what):
+            Library(wrong, mode="hip")
+    # macros: the srhd_2d kernels' two are settings of the prebuilt library; anything else cannot be honoured
+    Library(mode="hip", define_macros=dict(PLM_THETA=2.0, MACH_CEILING=100.0))
+    Library(mode="hip", define_macros=dict(PLM_THETA=1.5, MACH_CEILING=1e6))  # (back to the reference's defaults)
+    with pytest.raises(KernelError, match="prebuilt"):
+        Library(mode="hip", define_macros=dict(NCONS=4))
+    with pytest.raises(KernelError):
+        Library(mode="hip", define_macros=dict(PLM_THETA=3.0))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference sources not present")
+@pytest.mark.parametrize("solver", ["cbdiso_2d", "cbdgam_2d", "srhd_2d", "cbdisodg_2d"])
+def test_library_accepts_the_reference_solvers_own_code(solver):
+    """The text the reference's four solvers pass to Library -- their .c files, read where they lie -- passes the check."""
+    from sailfish_amd.kernel.library import Library
+
+    with open(f"/root/reference/sailfish/solvers/{solver}.c") as f:
+        lib = Library(f.read(), mode="hip", debug=False)
+    assert lib.declared and all(name.startswith(solver) for name in lib.declared)
