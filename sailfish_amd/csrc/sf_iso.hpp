@@ -472,7 +472,28 @@ __global__ __launch_bounds__(256, (WS == 0 && !UN) ? SFHIP_ISO_A0_WAVES : 3) voi
 #endif
         }
         __builtin_amdgcn_sched_barrier(0); // keep the requests first (the scheduler would sink them by ~150 instructions)
-#if defined(SFHIP_DIAG_NO_COMPUTE)  // diagnosis builds only (WRONG results): the march's memory traffic without its arithmetic
+#if defined(SFHIP_DIAG_NO_COMPUTE) && defined(SFHIP_DIAG_TWO_ROWS)  // the same traffic, two rows' requests in flight per wave
+        {
+            if ((r - I0) & 1) continue;
+            const double *s2 = row(r + 2);
+            double pq[3] = {s2[0], s2[1], s2[2]}, uq[3] = {0, 0, 0};
+            if (want_un) { const double *us = unsrc + (long)(r - 1) * si + ucol; uq[0] = us[0]; uq[1] = us[1]; uq[2] = us[2]; }
+            __builtin_amdgcn_sched_barrier(0);
+            double o[3], o2[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                o[q] = pa[q] + un[q]; o2[q] = pb[q] + uq[q];
+                pa[q] = pc[q]; pb[q] = pn[q]; pc[q] = pq[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (upd && store_lane) {
+                const long c = (long)(r - 2) * si + (long)J * sj;
+                pwr[c] = o[0]; pwr[c + 1] = o[1]; pwr[c + 2] = o[2];
+                pwr[c + si] = o2[0]; pwr[c + si + 1] = o2[1]; pwr[c + si + 2] = o2[2];
+            }
+            continue;
+        }
+#elif defined(SFHIP_DIAG_NO_COMPUTE)  // diagnosis builds only (WRONG results): the march's memory traffic without its arithmetic
         {
             double o[3];
 #pragma unroll
