@@ -502,7 +502,9 @@ class SolverBase:
         except Exception as exc:  # a missing library, a failed bootstrap: not fatal, the default transport remains
             error = exc
         torch = self._torch()
-        ok = torch.tensor([0.0 if comm is None else 1.0], dtype=torch.float64, device="cuda")
+        # (a tensor where the process group moves data: device memory on RCCL, host memory on gloo)
+        where = "cuda" if self.comm.dist.get_backend() == "nccl" else "cpu"
+        ok = torch.tensor([0.0 if comm is None else 1.0], dtype=torch.float64, device=where)
         self.comm.dist.all_reduce(ok, op=self.comm.dist.ReduceOp.MIN)
         if float(ok.item()) != 1.0:
             if comm is not None:

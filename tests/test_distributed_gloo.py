@@ -308,3 +308,64 @@ def test_nan_wavespeed_reaches_every_rank():
         assert p.exitcode == 0
     for rank, ok, err in results:
         assert ok, (rank, err)
+
+
+def _fallback_worker(rank, world, port, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_backend import OracleBackend
+        from sailfish_amd.kernel import rccl
+        from sailfish_amd.setups import make_setup
+        from sailfish_amd.solvers import make_solver
+
+        setup = make_setup("circumbinary-disk")
+        s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=setup.mesh(32), time=0.0, num_patches=world,
+                        backend=OracleBackend())
+        closed = []
+
+        class FakeComm:
+            def close(self):
+                closed.append(rank)
+
+        def create(dist_, rank_, size_):  # rank 1 cannot join (a missing library, a failed bootstrap ...)
+            if rank_ == 1:
+                raise rccl.RcclError("ncclCommInitRank failed: unhandled system error (simulated)")
+            return FakeComm()
+
+        rccl.RcclComm.create = staticmethod(create)
+        got = s._create_rccl()                    # collective
+        ok = got is None and closed == ([rank] if rank != 1 else [])  # everyone falls back; the ranks that joined close
+        rccl.RcclComm.create = staticmethod(lambda d, r, n: FakeComm())
+        ok &= isinstance(s._create_rccl(), FakeComm)  # and when every rank joins, every rank keeps its communicator
+        # the solver itself still steps on the default transport
+        dt = s.step(0.3)
+        queue.put((rank, bool(ok and dt > 0.0), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_rccl_falls_back_on_every_rank_when_one_cannot_join():
+    """`SolverBase._create_rccl`: every rank tries to join the direct RCCL communicator; if ANY rank fails (here rank 1
+    of 3, with the error RCCL gives for a failed bootstrap), all ranks drop it together -- the ranks that had joined
+    close theirs -- and carry on through torch.distributed; a transport chosen rank by rank would deadlock the first
+    exchange."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    results = [queue.get(timeout=5) for _ in range(world)]
+    for p in procs:
+        assert p.exitcode == 0
+    for rank, ok, err in results:
+        assert ok, (rank, err)
