@@ -338,3 +338,27 @@ def test_pair_from_a_developed_flow_at_384(model, spinup):
         cpu.advance(dt_cpu)
         assert abs(gpu.time - cpu.time) <= 1e-13 * abs(cpu.time)
     check(gpu.solution, cpu.solution)
+
+
+@pytest.mark.parametrize("model", [dict(domain_radius=3.3), dict(domain_radius=3.3, eos="gamma-law")], ids=["iso", "gam"])
+def test_wavespeed_is_bit_exact_on_a_mesh_whose_spacing_is_not_dyadic(model):
+    """Every other mesh in these tests spans [-12, 12] or a power of two, where (i + 0.5) dx is exact and a fused
+    multiply-add cannot differ from the reference's two roundings.  Here dx = 6.6 / 100: the zone coordinates the
+    fused epilogue's exact path uses must be the reference's `xl + (i + 0.5) * dx` in two roundings (`mesh_coord`,
+    round 3), or the reduced wavespeed differs from `cbdiso_2d_wavespeed` + max in the last place.  The fused
+    epilogue (state after a step), the standalone kernel on the same state and the oracle's kernel on the host copy
+    of that state give the same bits; so does dt."""
+    import oracle
+
+    setup = make_setup("circumbinary-disk", **model)
+    mesh = setup.mesh(100)
+    s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, mode="hip", num_patches=3)
+    cfl = s.recommended_cfl
+    for _ in range(5):
+        s.step(cfl)
+    fused = s.maximum_wavespeed()                      # folded by the last stage's epilogue
+    standalone = s._reduce_wavespeed(recompute=True)   # the reference-named wavespeed kernel + max
+    assert fused == standalone
+    cpu = ref_solver.OracleSolver(setup, mesh, time=s.time, solution=s.solution, num_patches=3)
+    assert cpu.maximum_wavespeed() == fused
+    assert timestep(mesh, s, cfl) == mesh.min_spacing() / fused * cfl
