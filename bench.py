@@ -33,6 +33,8 @@ Output fields beyond the driver's contract
                  `traffic`: HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
                  same workload, run by this command as child processes before it touches the GPU (N = 1; 3 steps
                  each); the committed profiles/traffic.json when such a pass is not possible, with the reason
+                 `copy_ceiling`: what a plain device copy of one state array's bytes reaches on this box, measured by
+                 this command after the timed region (N = 1), and the kernel's achieved rate over it
   roofline_valu  what actually binds: the kernel's fp64 VALU instruction stream (count per launch and the clock
                  under the kernel from two more such passes) against the issue rate of 1024 SIMDs
   cold_ms_per_step  the first K steps of a fresh solver after ONE untimed step (code-object load, exact wavespeed
@@ -373,6 +375,26 @@ def transport_proof(ranks, solver):
     return everyone
 
 
+def copy_ceiling_gbs(torch, nbytes, reps=30, warm=5):
+    """What a plain device copy of an array of `nbytes` reaches on this box right now (read + write bytes per second):
+    the practical ceiling of any kernel that streams HBM, beside the 8 TB/s peak the roofline fraction is quoted on."""
+    n = max(1, int(nbytes) // 8)
+    a = torch.rand(n, dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(warm):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    seconds = e0.elapsed_time(e1) * 1e-3 / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * 8.0 * n / seconds / 1e9
+
+
 def measure(args, ranks, solver_kind, resolution, steps, warmup, use_events, measure_cold=False):
     """Build the workload, run `warmup` untimed and `steps` timed steps between fences; MAX seconds over ranks."""
     torch = ranks.torch
@@ -629,6 +651,19 @@ def main():
         if "strong_scaling" in extras:
             # BASELINE.json's metric is quoted on this series: the same object under the name that says so
             extras["metric_config"] = extras["strong_scaling"]
+
+    if roofline is not None and world == 1 and not os.environ.get("SFHIP_BENCH_CHILD"):
+        # the same device, right after the timed region: a copy of one state array's worth of bytes
+        try:
+            ceiling = copy_ceiling_gbs(ranks.torch, head["zones"] * 8.0 * NCONS[args.solver])
+            roofline["copy_ceiling"] = dict(
+                value=round(ceiling, 1), unit="GB/s", frac_of_peak=round(ceiling / HBM_PEAK_GBS, 4),
+                achieved_over_copy=round(roofline["achieved"] / ceiling, 4),
+                note="torch device copy of one state array's bytes, read + write, 30 repetitions, measured by this "
+                     "command after the timed region: what streaming reaches on this box; `frac` stays the fraction "
+                     "of the 8 TB/s peak")
+        except Exception as exc:  # a report, never a reason to lose the line
+            roofline["copy_ceiling"] = dict(failed=repr(exc))
 
     cpu = None
     if ranks.rank == 0 and world == 1 and not args.no_cpu_baseline:
