@@ -528,7 +528,11 @@ def roofline_of(args, run, world):
         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
         kernel=kernel, launches=launches, avg_launch_ms=round(ms / launches, 4),
         algorithmic_bytes_per_launch=round(alg_bytes / launches),
-        binding="fp64 VALU issue, not HBM: see roofline_valu and DESIGN.md section 5",
+        binding={"iso": "balanced between the fp64 instruction stream (0.41 ms per RK2 pair alone) and the memory traffic "
+                        "(0.45 ms alone, at 0.85-0.9 of the copy ceiling); together 0.50: DESIGN.md sections 3.1 and 5",
+                 "gam": "fp64 VALU issue at two waves per SIMD (instruction stream alone 0.82 of 0.96 ms, memory traffic "
+                        "alone 0.58): see roofline_valu and DESIGN.md section 5"}.get(
+                     args.solver, "fp64 VALU issue, not HBM: see roofline_valu and DESIGN.md"),
         note=f"launch durations: HIP events around every launch of every {run['stride']}. timed step "
              f"({len(log)} launches inside the timed region), minus the median of 40 empty brackets "
              f"({over * 1e3:.1f} us) measured on the same stream right after the timed region; a bracketed launch "
