@@ -283,6 +283,9 @@ template <int WS, bool UN, bool FULL>
 #if !defined(SFHIP_ISO_A0_WAVES)
 #define SFHIP_ISO_A0_WAVES 3
 #endif
+#if defined(SFHIP_DIAG_ISO_TWO_WAVES)  // diagnosis builds only: what the third resident wave per SIMD is worth
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 __global__ __launch_bounds__(256, (WS == 0 && !UN) ? SFHIP_ISO_A0_WAVES : 3) void iso_stage_kernel(
     IsoParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
