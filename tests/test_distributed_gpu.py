@@ -384,7 +384,21 @@ def _thread_ranks_worker(kind, world, patches_per_rank, queue):
                 amax = s.maximum_wavespeed()
                 torch.cuda.synchronize()
                 rows = np.concatenate([p.primitive1[2:-2, 2:-2].cpu().numpy() for p in s.patches], axis=0)
-            results[rank] = (dts, amax, rows, s.time)
+                died_at = None
+                if kind == "gam":
+                    # a state that blows up on ONE rank must stop ALL of them, at the same step, the way the one-rank
+                    # step stops (NaN wavespeed -> NaN dt -> the Kepler solve's ValueError): the slot is reduced over
+                    # the ranks as bit patterns, so the NaN reaches everybody
+                    if rank == world - 1:
+                        s.patches[0].primitive1[7, 9, 3] = float("nan")
+                    for k in range(4):
+                        try:
+                            s.step(cfl)
+                        except ValueError as exc:
+                            assert "NaN" in str(exc) or "nan" in str(exc)
+                            died_at = k
+                            break
+            results[rank] = (dts, amax, rows, s.time, died_at)
         except BaseException as exc:  # noqa: BLE001 -- reported by the parent
             import traceback
 
@@ -399,13 +413,20 @@ def _thread_ranks_worker(kind, world, patches_per_rank, queue):
     if errors or any(t.is_alive() for t in threads) or any(r is None for r in results):
         queue.put((0, float("inf"), repr(errors)[:3000], None))
         os._exit(1)  # (a rank thread may still be blocked inside the library)
-    ok = all(r[0] == expect_dt and r[1] == expect_amax and r[3] == one.time for r in results)
+    ok = all(r[0] == expect_dt and r[1] == expect_amax for r in results)
+    if kind == "gam":  # every rank died, and at the same step (the step after the one that folded the NaN)
+        ok = ok and all(r[4] is not None and r[4] == results[0][4] for r in results)
+    else:
+        ok = ok and all(r[3] == one.time for r in results)
     ok = ok and bool(np.array_equal(np.concatenate([r[2] for r in results], axis=0), expect))
     counts = (ctypes.c_long * 4)()
     mock.mock_rccl_counts(MockRccl(0).comm, counts)
     # every step: 2 stages x 2 slabs per interior seam between ranks, one all-reduce; nothing left unmatched
     seams = world - 1
-    ok = ok and counts[0] == counts[1] == steps * 2 * 2 * seams and counts[2] == steps and counts[3] == 0
+    if kind == "gam":
+        ok = ok and counts[0] == counts[1] and counts[3] == 0  # (the dying steps exchange too: matched, none left)
+    else:
+        ok = ok and counts[0] == counts[1] == steps * 2 * 2 * seams and counts[2] == steps and counts[3] == 0
     queue.put((0, 0.0 if ok else float("inf"), list(counts), None))
 
 
@@ -421,7 +442,9 @@ def test_step_group_with_neighbours_on_other_ranks(kind, world, patches_per_rank
     edges against neighbours, several patches per rank (local copies and remote slabs in one stage), streams and
     events, where the all-reduce sits, and the Python side of a rank with comm.enabled.  Equal to the one-process run
     of the same decomposition bit for bit -- dt sequence, reduced wavespeed, final state -- with exactly the expected
-    number of messages and none left over.
+    number of messages and none left over.  cbdgam_2d then poisons one zone on the LAST rank: every rank's step fails
+    with the Kepler solve's NaN error at the same step (the slot is reduced over the ranks as bit patterns), none
+    carries on alone.
     """
     for _, err, detail, _ in _run_ranks(_thread_ranks_worker, lambda r: (kind, world, patches_per_rank), world=1, timeout=150):
         assert err == 0.0, detail
