@@ -447,7 +447,13 @@ class SolverBase:
             elif (len({str(p.primitive1.device) for p in self.patches}) == 1
                   and (self._rccl is not None or not self.comm.enabled)
                   and all(p.shape[0] >= 2 * NG for p in self.patches)):
-                self._group = self._create_step_group(setup)
+                try:
+                    self._group = self._create_step_group(setup)
+                except Exception as exc:
+                    # Not fatal: the Python stages issue the same exchanges in the same order over the same
+                    # communicator (a rank stepping from C and a rank stepping from Python stay in step), only slower.
+                    logger.warning(f"no C step group ({exc!r}); the stages are driven from Python")
+                    self._group = None
         self._mass_cache = (None, None)
         self._wavespeed_floor = 0.0
         self._dt_dev = None
