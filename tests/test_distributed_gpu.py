@@ -288,7 +288,7 @@ def test_step_group_self_exchange(kind):
         assert err == 0.0, (worst, timing)
 
 
-def _thread_ranks_worker(kind, world, patches_per_rank, queue):
+def _thread_ranks_worker(kind, world, patches_per_rank, queue, mixed=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import ctypes
@@ -346,11 +346,18 @@ def _thread_ranks_worker(kind, world, patches_per_rank, queue):
             self.enabled, self.rank, self.size, self.dist = True, rank, world, RankDist(rank)
             self._host_group, self._staged = None, None
 
-    class MockRccl:
-        """What SolverBase and StepGroup ask of kernel/rccl.py's RcclComm, on the mock library."""
+    from sailfish_amd.kernel.rccl import RcclComm
+
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    mock.ncclSend.argtypes = mock.ncclRecv.argtypes = [vp, sz, ci, ci, vp, vp]
+    mock.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+    mock.ncclGetErrorString.argtypes, mock.ncclGetErrorString.restype = [ci], ctypes.c_char_p
+    mock.sfhip_path = mock_path
+
+    class MockRccl(RcclComm):
+        """kernel/rccl.py's RcclComm (exchange, max_scalar: what the Python stages call) on the mock library."""
         def __init__(self, rank):
-            self.comm = ctypes.c_void_p(mock.mock_rccl_comm(rank, world))
-            self.rank, self.size, self.library_path = rank, world, mock_path
+            super().__init__(mock, ctypes.c_void_p(mock.mock_rccl_comm(rank, world)), rank, world)
 
         def count(self):
             return self.size, self.rank
@@ -380,6 +387,10 @@ def _thread_ranks_worker(kind, world, patches_per_rank, queue):
                 s = make_solver(setup.solver, setup.physics, {}, setup=setup, mesh=mesh, time=0.0, num_patches=num_patches,
                                 mode="hip")
                 assert s._group is not None and s.halo_transport == "rccl" and len(s.patches) == patches_per_rank
+                if mixed and rank % 2 == 1:
+                    # this rank lost its step group (see SolverBase._setup_patches): it drives the stages from Python,
+                    # through the same communicator, while its neighbours step from C
+                    s._group = None
                 dts = [s.step(cfl) for _ in range(steps)]
                 amax = s.maximum_wavespeed()
                 torch.cuda.synchronize()
@@ -430,8 +441,13 @@ def _thread_ranks_worker(kind, world, patches_per_rank, queue):
     queue.put((0, 0.0 if ok else float("inf"), list(counts), None))
 
 
-@pytest.mark.parametrize("kind,world,patches_per_rank", [("iso", 2, 1), ("iso", 3, 2), ("gam", 2, 2)])
-def test_step_group_with_neighbours_on_other_ranks(kind, world, patches_per_rank):
+def _thread_ranks_worker_mixed(kind, world, patches_per_rank, queue):
+    _thread_ranks_worker(kind, world, patches_per_rank, queue, mixed=True)
+
+
+@pytest.mark.parametrize("kind,world,patches_per_rank,mixed", [("iso", 2, 1, False), ("iso", 3, 2, False), ("gam", 2, 2, False),
+                                                              ("iso", 3, 1, True)])
+def test_step_group_with_neighbours_on_other_ranks(kind, world, patches_per_rank, mixed):
     """
     sfhip_step_group_rk2 with REAL neighbours: two or three "ranks" that are threads of one process on the one GPU,
     each with its own stream, its own step group and a different rank number, exchanging their slabs and reducing
@@ -444,7 +460,10 @@ def test_step_group_with_neighbours_on_other_ranks(kind, world, patches_per_rank
     of the same decomposition bit for bit -- dt sequence, reduced wavespeed, final state -- with exactly the expected
     number of messages and none left over.  cbdgam_2d then poisons one zone on the LAST rank: every rank's step fails
     with the Kepler solve's NaN error at the same step (the slot is reduced over the ranks as bit patterns), none
-    carries on alone.
+    carries on alone.  `mixed`: the odd ranks step through the Python stages instead (what a rank does whose step group
+    could not be made): the same exchanges in the same order, so C-stepping and Python-stepping ranks stay in step.
     """
-    for _, err, detail, _ in _run_ranks(_thread_ranks_worker, lambda r: (kind, world, patches_per_rank), world=1, timeout=150):
+    args = (kind, world, patches_per_rank)
+    for _, err, detail, _ in _run_ranks(_thread_ranks_worker, lambda r: args, world=1, timeout=150) if not mixed else \
+            _run_ranks(_thread_ranks_worker_mixed, lambda r: args, world=1, timeout=150):
         assert err == 0.0, detail
