@@ -4,8 +4,9 @@
 //   * One wave owns a strip of 64 columns (60 outputs + 2 halo lanes per side)
 //     and marches down a chunk of rows.  The x-direction stencil (reach 2) lives
 //     in a register window that slides with the march; the y-direction stencil
-//     is the neighbouring lanes, reached with DPP wave shifts.  No LDS, no
-//     barriers; every primitive row is loaded from HBM once per strip.
+//     is the neighbouring lanes, reached with DPP wave shifts.  No LDS tiles, no
+//     barriers; every primitive row is loaded from HBM once per strip.  (LDS holds
+//     one small per-wave table of the rows' lane-independent quantities, round 3.)
 //   * Slopes are evaluated once per zone and HLLE fluxes once per face (the
 //     reference evaluates every face twice, cbdiso_2d.c:525-563); both views
 //     perform identical IEEE operations, so results agree bit-for-bit wherever
