@@ -385,6 +385,9 @@ template <bool WS, bool UN, bool FULL>
 #ifndef SFHIP_GAM_WAVES
 #define SFHIP_GAM_WAVES 2
 #endif
+#if defined(SFHIP_DIAG_GAM_TWO_WAVES)  // diagnosis builds only: hold a kernel that would fit three waves per SIMD to two
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
     GamParams P, const double *__restrict__ prd, const double *unsrc,
     double *pwr, double *__restrict__ wmax, int nstrips, int nchunks)
@@ -407,7 +410,11 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
     const int ni = P.ni, nj = P.nj;
     const long sj = 4, si = 4L * (nj + 2 * NG);
     const double gamma = P.gamma;
+#if defined(SFHIP_DIAG_NO_VISC)  // diagnosis builds only (WRONG results)
+    const bool visc = false;
+#else
     const bool visc = FULL || P.alpha > 0.0;
+#endif
     const bool hvar = FULL || P.any_mass != 0; // disk height varies in space
 
     const int J = strip * STRIP + lane;
@@ -616,10 +623,12 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                 // disk_height at the zone centre is only consumed by non-constant softening
                 double hcc = 1.0;
                 if (!P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast<FULL>(P.m, ea[2], ea[3], oyc0, oyc1);
+#if !defined(SFHIP_DIAG_NO_SOURCES)  // diagnosis builds only (WRONG results): a kernel that fits three waves per SIMD
                 gam_buffer_fast<FULL>(P, xc, yc, yc2, u);
                 gam_mass_source_fast<FULL>(P.m[0], P.sink_near2[0], &Pk->m[0], ea[2], dyc0, P.dt, pa, eps, hcc, u, P.constant_softening);
                 gam_mass_source_fast<FULL>(P.m[1], P.sink_near2[1], &Pk->m[1], ea[3], dyc1, P.dt, pa, eps, hcc, u, P.constant_softening);
                 gam_cooling_fast(P, pa, eps, rinva, u);
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) u[q] += tot[q];
                 if (UN) {
