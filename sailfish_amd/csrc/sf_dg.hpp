@@ -49,6 +49,7 @@ struct DgParams {
     double cs2, mach2;
     double nu, rk, dt, vmax;
     int clamp_lo, clamp_hi, clamp_j, i_begin, i_end, want_ws;
+    int rows_per_wave;          // rows a wave of dg_advance_kernel marches up
     double wx[2], wy[2], wm[2], wrs[2]; // point masses of the wavespeed epilogue
     const double *dt_ptr;
 };
@@ -303,9 +304,300 @@ __device__ __forceinline__ void dg_load(const double *zone, double (&w)[3][DG_K]
 
 // ---------------------------------------------------------------------------------------------
 // cbdisodg_2d_advance_rk, :607-983 (+ index clamps, device dt and wavespeed epilogue; sfhip.h)
+//
+// Every face once (almost).  The reference's zone evaluates the Riemann problems of its four faces itself, so each
+// face is solved twice, by the zones on either side of it -- with the same operands in the same order: both see
+// the low-side zone's trace as `um` and the high-side zone's as `up`, both subtract the high-side zone's viscous
+// stress first (:860-869).  The ONLY thing that can differ between the two evaluations is the position the sound
+// speed is taken at: the face node as xc + 0.5 dx of the zone below or as xc - 0.5 dx of the zone above, which agree
+// to rounding, not always bit for bit.  Here a wave owns 63 columns (lane 63 owns no zone: it provides lane 62's
+// high y-face) and marches up `rows_per_wave` rows.  For a row it goes through the twelve face nodes in the
+// reference's order -- per Gauss node: xl, xr, yl, yr -- adding to the surface integral as it goes, but SOLVES only
+//   xr  between this row and the next: the fluxes as this row sees them, and as the next row will see them as its
+//       xl (kept in LDS for the next iteration; the sound speed at the next row's position -- when both positions
+//       are the same doubles in every lane, always the case for a globally isothermal gas and for dyadic mesh
+//       spacings, the second solve is skipped);
+//   yl  between the lane to the left and this lane: as this lane sees them, and as the left lane sees them as its
+//       yr, which that lane fetches with one lane shift per component;
+//   xl  only in the first row of the march (the row below belongs to another wave, which solves that face again).
+// 12 -> 6 + 3 / rows_per_wave face nodes per zone; every wave is its own workgroup, no barrier, 4.6 KB of LDS.
+// (A tile of 4 rows x 63 columns with one wave per row and the x-faces exchanged through LDS behind a barrier was
+// built first: 6.75 face nodes per zone, 24 % fewer instructions, but 10 % less time only -- the barrier and the
+// waves that solve the tile's upper edge cost 6 % and 8 %.)
+// Results are those of the zone kernel bit for bit (tests/test_hip_dg.py).
+// grid: (ceil(nj / 63), ceil((i_end - i_begin) / rows_per_wave)), block 64
+// ---------------------------------------------------------------------------------------------
+
+// One face node between two zones whose weights are `a` (this wave's row / this lane) and `b` (the zone on the other
+// side, loaded here from `b_at`).  `swap` false: `a` is the zone ABOVE the face (the face is a's low face `fn`);
+// true: `a` is the zone BELOW it (the face is b's low face `fn`).  fa: the fluxes with the sound speed at (xa, ya),
+// a's own position of the node; fb: with it at (xb, yb), b's -- solved only if `both` and the positions differ.
+__device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a)[3][DG_K], const double *b_at, int fn,
+                                             bool ydir, bool swap, bool both, double xa, double ya, double xb, double yb,
+                                             const DgRcp &rmach2, const DgRcp &rdx, const DgRcp &rdy,
+                                             const double (&mx)[2], const double (&my)[2], const double (&mm)[2],
+                                             const double (&mrs)[2], bool viscous, double (&fa)[3], double (&fb)[3])
+{
+    double b[3][DG_K];
+    dg_load(b_at, b);
+    const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, xa, ya, mx, my, mm, mrs);
+    // the traces: the zone above the face through its low-end basis, the zone below through its high-end basis
+    const double(*tab_a)[DG_K] = swap ? dg_tab.face_nb : dg_tab.face_own;
+    const double(*tab_b)[DG_K] = swap ? dg_tab.face_own : dg_tab.face_nb;
+    double ua[3], ub[3];
+    dg_eval<63>(a, tab_a[fn], ua);
+    dg_eval<63>(b, tab_b[fn], ub);
+    const DgRcp ra = dg_rcp(ua[0]), rb = dg_rcp(ub[0]);
+    double up[3], um[3]; // high-side and low-side traces
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        up[c] = swap ? ub[c] : ua[c];
+        um[c] = swap ? ua[c] : ub[c];
+    }
+    const DgRcp rp = {up[0], swap ? rb.r : ra.r}, rm = {um[0], swap ? ra.r : rb.r};
+    double pl[3], pr[3];
+    dg_c2p(um, rm, pl, P.vmax);
+    dg_c2p(up, rp, pr, P.vmax);
+    const double e0 = ydir ? 0.0 : 1.0, e1 = ydir ? 1.0 : 0.0;
+    const double vl = ydir ? pl[2] : pl[1], vr = ydir ? pr[2] : pr[1];
+    double h1 = 0.0, h2 = 0.0, l1 = 0.0, l2 = 0.0; // viscous stresses of the high-side and the low-side zone
+    if (viscous) {
+        // the face-normal "gradient" IS the trace
+        const double(*tan_a)[DG_K] = swap ? dg_tab.face_nb_t : dg_tab.face_own_t;
+        const double(*tan_b)[DG_K] = swap ? dg_tab.face_own_t : dg_tab.face_nb_t;
+        double ta[3], tb[3];
+        dg_eval<63>(a, tan_a[fn], ta);
+        dg_eval<63>(b, tan_b[fn], tb);
+        double gxa[3], gya[3], gxb[3], gyb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gxa[c] = ydir ? ta[c] : ua[c];
+            gya[c] = ydir ? ua[c] : ta[c];
+            gxb[c] = ydir ? tb[c] : ub[c];
+            gyb[c] = ydir ? ub[c] : tb[c];
+        }
+        double axx, axy, ayy, bxx, bxy, byy;
+        dg_stress(ua, ra, gxa, gya, P.nu, rdx, rdy, axx, axy, ayy);
+        dg_stress(ub, rb, gxb, gyb, P.nu, rdx, rdy, bxx, bxy, byy);
+        const double a1 = ydir ? axy : axx, a2 = ydir ? ayy : axy;
+        const double b1 = ydir ? bxy : bxx, b2 = ydir ? byy : bxy;
+        h1 = swap ? b1 : a1; h2 = swap ? b2 : a2;
+        l1 = swap ? a1 : b1; l2 = swap ? a2 : b2;
+    }
+    // riemann_hlle, :295-324, and the viscous fluxes: high side first, then low side (:860-869)
+    auto solve = [&](double c2, double (&fhat)[3]) {
+        double fl[3], fr[3];
+        dg_flux(pl, um, c2, vl, e0, e1, fl);
+        dg_flux(pr, up, c2, vr, e0, e1, fr);
+        const double cs = exact_sqrt0(c2);
+        const double am = min2(0.0, min2(vl - cs, vr - cs));
+        const double ap = max2(0.0, max2(vl + cs, vr + cs));
+        const DgRcp rspan = dg_rcp(ap - am);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            fhat[c] = dg_div(fl[c] * ap - fr[c] * am - (um[c] - up[c]) * ap * am, rspan);
+        if (viscous) {
+            fhat[1] -= h1;
+            fhat[2] -= h2;
+            fhat[1] -= l1;
+            fhat[2] -= l2;
+        }
+    };
+    solve(cs2, fa);
+    bool differs = false;
+#if !defined(SFHIP_DIAG_DG_ONE_VIEW)  // diagnosis builds only (WRONG in the last place): checks that the tests see the second view
+    if (both && P.eos == 2) differs = xb != xa || yb != ya;
+#endif
+    if (__builtin_amdgcn_ballot_w64(differs) != 0) { // (wave-uniform)
+        const double cs2b = dg_cs2(P.cs2, rmach2, P.eos, xb, yb, mx, my, mm, mrs);
+        solve(cs2b, fb);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fb[c] = fa[c];
+    }
+}
+
+__global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double *__restrict__ weights0,
+                                                        const double *__restrict__ weights1,
+                                                        double *__restrict__ weights2, double *wavespeed_max)
+{
+    // the fluxes through the next row's low x-face as that row sees them: [node][field][lane]
+    __shared__ double next_xl[3][3][64];
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 63 + lane;
+    const int i_first = P.i_begin + blockIdx.y * P.rows_per_wave;
+    const int i_stop = i_first + P.rows_per_wave < P.i_end ? i_first + P.rows_per_wave : P.i_end;
+    const bool present = j <= P.nj;            // solves its low y-face
+    const bool owner = lane < 63 && j < P.nj;  // updates zones
+    const long sj = DG_NW, si = (long)DG_NW * (P.nj + 2);
+    const double dx = P.dx, dy = P.dy;
+    const double mx[2] = {P.m[0].x, P.m[1].x}, my[2] = {P.m[0].y, P.m[1].y};
+    const double mm[2] = {P.m[0].mass, P.m[1].mass}, mrs[2] = {P.m[0].rsoft, P.m[1].rsoft};
+    const bool viscous = P.nu > 0.0;
+    const DgRcp rdx = dg_rcp(dx), rdy = dg_rcp(dy), rmach2 = dg_rcp(P.mach2), rvol = dg_rcp(P.cell_volume);
+    const double dt = P.dt_ptr ? *P.dt_ptr : P.dt;
+    const double yc = P.yl + (j + 0.5) * dy;
+    const double yc_left = P.yl + ((j - 1) + 0.5) * dy; // the left lane's own centre, formed as that lane forms it
+    // an outflow edge's guard zone is a copy of the edge zone itself: the lane beyond the edge (it only provides the
+    // edge zone's high y-face) then IS the edge zone
+    const int ja = (P.clamp_j && j == P.nj) ? j - 1 : j;
+    double speed = 0.0;
+
+    if (present) {
+#pragma unroll 1
+        for (int i = i_first; i < i_stop; ++i) {
+            const long at = (long)(i + 1) * si + (ja + 1) * sj;
+            double cc[3][DG_K];
+            dg_load(weights1 + at, cc);
+            const double xc = P.xl + (i + 0.5) * dx;
+            const double xc_up = P.xl + ((i + 1) + 0.5) * dx; // the next row's own centre, formed as that row forms it
+            // the zones on the other side of the faces that are solved here
+            const long below_x = (P.clamp_lo && i == 0) ? at : at - si;
+            const long above_x = (P.clamp_hi && i == P.ni - 1) ? at : at + si;
+            const long left_y = (P.clamp_j && j == 0) ? at : (long)(i + 1) * si + j * sj; // (column j is zone j - 1)
+
+            // ---- surface integral, :848-961: per Gauss node the faces xl, xr, yl, yr ----------
+            double srf[3][DG_K]; // equation_20
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int k = 0; k < DG_K; ++k) srf[q][k] = 0.0;
+            double yr[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int fn = 0; fn < 12; ++fn) {
+                const int face = fn & 3, q = fn >> 2;
+                const bool high = face & 1, ydir = face >> 1;
+                double fhat[3];
+                if (face == 3) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) fhat[c] = yr[c];
+                } else if (face == 0 && i != i_first) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) fhat[c] = next_xl[q][c][lane];
+                } else {
+                    const double x = xc + dg_tab.face_cx[fn] * dx; // the node as this zone places it
+                    const double y = yc + dg_tab.face_cy[fn] * dy;
+                    double fother[3];
+                    if (face == 1) {
+                        // as the next row's low x-face: its table row, its position of the node
+                        const int fu = q * 4;
+                        const double xu = xc_up + dg_tab.face_cx[fu] * dx;
+                        const double yu = yc + dg_tab.face_cy[fu] * dy;
+                        dg_face_node(P, cc, weights1 + above_x, fu, false, true, i + 1 < i_stop, x, y, xu, yu, rmach2, rdx, rdy,
+                                     mx, my, mm, mrs, viscous, fhat, fother);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) next_xl[q][c][lane] = fother[c];
+                    } else if (face == 2) {
+                        // the left lane sees this face as its high y-face fn + 1
+                        const double xl_ = xc + dg_tab.face_cx[fn + 1] * dx;
+                        const double yl_ = yc_left + dg_tab.face_cy[fn + 1] * dy;
+                        dg_face_node(P, cc, weights1 + left_y, fn, true, false, true, x, y, xl_, yl_, rmach2, rdx, rdy, mx, my, mm,
+                                     mrs, viscous, fhat, fother);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) yr[c] = from_lane_above(fother[c]); // the high y-face of THIS lane's zone
+                    } else {
+                        dg_face_node(P, cc, weights1 + below_x, fn, false, false, false, x, y, x, y, rmach2, rdx, rdy, mx, my, mm,
+                                     mrs, viscous, fhat, fother);
+                    }
+                }
+                const double len = ydir ? dx : dy;
+                const double gw = dg_tab.face_gw[fn];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int k = 0; k < DG_K; ++k) {
+                        double term = len * fhat[c] * dg_tab.face_own[fn][k] * gw;
+                        srf[c][k] += high ? term : -term;
+                    }
+                }
+            }
+            if (!owner) continue;
+
+            // ---- volume integral and sources, :776-844 ---------------------------------------
+            double vol[3][DG_K], src[3][DG_K]; // equation_19, source_weights
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int k = 0; k < DG_K; ++k) vol[q][k] = src[q][k] = 0.0;
+#pragma unroll 1
+            for (int nd = 0; nd < 9; ++nd) {
+                const double x = xc + dg_tab.vol_cx[nd] * dx;
+                const double y = yc + dg_tab.vol_cy[nd] * dy;
+                const double gw = dg_tab.vol_gw[nd];
+                const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, x, y, mx, my, mm, mrs);
+                double u[3], p[3], fx[3], fy[3];
+                dg_eval<63>(cc, dg_tab.vol_phi[nd], u);
+                const DgRcp ru = dg_rcp(u[0]);
+                dg_c2p(u, ru, p, P.vmax);
+                dg_flux(p, u, cs2, p[1], 1.0, 0.0, fx);
+                dg_flux(p, u, cs2, p[2], 0.0, 1.0, fy);
+                if (viscous) {
+                    double ux[3], uy[3], txx, txy, tyy;
+                    dg_eval<0x38>(cc, dg_tab.vol_dpx[nd], ux); // m >= 1: slots 3, 4, 5
+                    dg_eval<0x16>(cc, dg_tab.vol_dpy[nd], uy); // n >= 1: slots 1, 2, 4
+                    dg_stress(u, ru, ux, uy, P.nu, rdx, rdy, txx, txy, tyy);
+                    fx[1] -= txx;
+                    fx[2] -= txy;
+                    fy[1] -= txy;
+                    fy[2] -= tyy;
+                }
+#pragma unroll
+                for (int k = 1; k < DG_K; ++k) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        if (0x38 & (1 << k)) vol[q][k] += dx * fx[q] * dg_tab.vol_dpx[nd][k] * gw;
+                        if (0x16 & (1 << k)) vol[q][k] += dy * fy[q] * dg_tab.vol_dpy[nd][k] * gw;
+                    }
+                }
+                double du[3] = {0.0, 0.0, 0.0};
+                dg_buffer_source(P, x, y, dt, u, du);
+                dg_mass_source(P.m[0], x, y, dt, p, du);
+                dg_mass_source(P.m[1], x, y, dt, p, du);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int k = 0; k < DG_K; ++k)
+                        src[q][k] += 0.25 * du[q] * dg_tab.vol_phi[nd][k] * gw;
+            }
+
+            // ---- :963-981 -------------------------------------------------------------------------
+            const double *w0 = weights0 + at;
+            double *w2 = weights2 + at;
+            double avg[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int k = 0; k < DG_K; ++k) {
+                    const int s = q * 9 + DG_SLOT[k];
+                    double wn = cc[q][k] + dg_div((vol[q][k] - srf[q][k]) * 0.5 * dt, rvol) + src[q][k];
+                    wn = (1.0 - P.rk) * wn + P.rk * w0[s];
+                    w2[s] = wn;
+                    if (k == 0) avg[q] = wn;
+                }
+            }
+
+            if (P.want_ws) { // cbdisodg_2d_wavespeed (:1152-1175) of the zone just written
+                double pa[3];
+                dg_c2p(avg, dg_rcp(avg[0]), pa, P.vmax);
+                double cs2 = dg_cs2(P.cs2, rmach2, P.eos, xc, yc, P.wx, P.wy, P.wm, P.wrs);
+                speed = max_nan(speed, max_speed(pa[1], pa[2], cs2));
+            }
+        }
+    }
+    if (P.want_ws) {
+        speed = wave_max_nonneg(speed);
+        // a plain load first skips the same-address atomic for every wave that cannot raise the maximum any more
+        if (lane == 0 && !(speed <= *(volatile double *)wavespeed_max)) atomic_max_nonneg(wavespeed_max, speed);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cbdisodg_2d_advance_rk, :607-983, the form of rounds 1-2: one lane per zone, every zone evaluates its four faces
+// itself (as the reference does), so every face is evaluated twice.  Kept behind SFHIP_DG_ZONE_KERNEL=1 for A/B
+// timing against dg_advance_kernel below, whose results are the same bit for bit.
 // grid: (ceil(nj / 64), i_end - i_begin), block 64
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double *__restrict__ weights0,
+__global__ __launch_bounds__(64) void dg_advance_zone_kernel(DgParams P, const double *__restrict__ weights0,
                                                         const double *__restrict__ weights1,
                                                         double *__restrict__ weights2, double *wavespeed_max)
 {

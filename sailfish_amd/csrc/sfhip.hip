@@ -1875,7 +1875,22 @@ int dg_stage_impl(
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
     if (i_end == i_begin) return 0;
-    dim3 block(64), grid((nj + 63) / 64, i_end - i_begin);
+    const bool zone_kernel = env_int("SFHIP_DG_ZONE_KERNEL", 0) != 0; // rounds 1-2: every zone solves its four faces (read per call: tests switch)
+    if (zone_kernel) {
+        dim3 block(64), grid((nj + 63) / 64, i_end - i_begin);
+        hipLaunchKernelGGL(sf::dg_advance_zone_kernel, grid, block, 0, t_stream, P, weights0, weights1, weights2, wavespeed_max);
+        return check_launch(who);
+    }
+    // one wave per 63 columns x rows_per_wave rows (the 64th lane only solves faces).  A long march solves fewer faces
+    // twice (6 + 3 / rows face nodes per zone); a patch with few rows keeps enough waves to fill the device.
+    const int nstrips = (nj + 62) / 63, nrows = i_end - i_begin;
+    int rpw = env_int("SFHIP_DG_ROWS_PER_WAVE", 0);
+    if (rpw <= 0) {
+        rpw = (int)((long)nrows * nstrips / 16384); // (2048^2: 2, 4 and 8 rows run alike, 16 leave too few waves)
+        rpw = rpw < 1 ? 1 : rpw > 8 ? 8 : rpw;
+    }
+    P.rows_per_wave = rpw;
+    dim3 block(64), grid(nstrips, (nrows + rpw - 1) / rpw);
     hipLaunchKernelGGL(sf::dg_advance_kernel, grid, block, 0, t_stream, P, weights0, weights1, weights2, wavespeed_max);
     return check_launch(who);
 }

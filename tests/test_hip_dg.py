@@ -126,6 +126,47 @@ def test_dg_clamped_rows_and_epilogue(kw, orc, hip_lib):
     assert host(d_max)[0] == speeds.max()
 
 
+@pytest.mark.parametrize("kw", [dict(ni=21, nj=130, extent=(-1.7, 1.3, -2.1, 2.9)),
+                                dict(ni=9, nj=63, extent=(-1.0, 2.0, -0.7, 0.9), nu=0.01, rk_param=0.5),
+                                dict(ni=6, nj=64, eos=1, extent=(-1.1, 1.1, -1.3, 1.3)),
+                                dict(ni=33, nj=200, extent=(-2.0, 2.0, -2.0, 2.0), sink_model=1)], ids=IDS)
+@pytest.mark.parametrize("clamped", [False, True], ids=["guards", "clamped"])
+@pytest.mark.parametrize("rows_per_wave", [1, 3, 8])
+def test_dg_faces_solved_once_equal_faces_solved_twice(kw, clamped, rows_per_wave, hip_lib, monkeypatch):
+    """
+    dg_advance_kernel solves a face once for the zones on both sides of it, wherever both belong to the same wave's
+    march (sf_dg.hpp; every `rows_per_wave` rows a face is still solved twice); the only thing the two sides can
+    disagree on is the position at which the sound speed is taken (locally isothermal gas, mesh spacing that is not
+    a power of two: the cases here).  With the point masses on, the oracle pins the update to 1e-12 only
+    (device pow / exp), so this property is pinned against the kernel of rounds 1-2, in which every zone solves its
+    own four faces as the reference's zones do (SFHIP_DG_ZONE_KERNEL=1): same device functions, so `==`,
+    on whole patches and on row ranges, with guard zones and with index clamps.
+    """
+    c = cases.dg_case(seed=41, **kw)
+    ni, nj = c["shape"]
+    w1 = c["w1"] if not clamped else fill_guards(c["w1"])
+    m1, m2 = c["m1"], c["m2"]
+    flags = (1, 1, 1) if clamped else (0, 0, 0)
+    outs = []
+    for zone_kernel in ("1", "0"):
+        monkeypatch.setenv("SFHIP_DG_ZONE_KERNEL", zone_kernel)
+        monkeypatch.setenv("SFHIP_DG_ROWS_PER_WAVE", str(rows_per_wave))
+        src = w1.copy()
+        if clamped:  # the clamps must keep both kernels away from the guard zones
+            src[0] = src[-1] = np.nan
+            src[:, 0] = src[:, -1] = np.nan
+        d_out, d_max, d_dt = dev(np.full_like(w1, -7.0)), dev(np.zeros(1)), dev(np.full(1, c["dt"]))
+        args = cases.dg_advance_args(c, dev(c["w0"]), dev(src), d_out)
+        for lo, hi, want in ((0, 5, 2), (5, ni - 1, 1), (ni - 1, ni, 1)):
+            hip_lib.sfhip_cbdisodg_2d_stage[c["shape"]](
+                *args, *flags, lo, hi, want, m1[0], m1[1], m1[4], m1[5], m2[0], m2[1], m2[4], m2[5], d_max, d_dt)
+        outs.append((host(d_out), host(d_max)[0]))
+    (a, amax), (b, bmax) = outs
+    assert np.isfinite(a[1:-1, 1:-1]).all()
+    assert np.array_equal(a, b)
+    assert amax == bmax
+
+
 def test_dg_full_size_properties(hip_lib):
     """
     2048^2 zones (too slow for the CPU oracle): a uniform state at rest without masses is a fixed
