@@ -328,25 +328,31 @@ __device__ __forceinline__ void dg_load(const double *zone, double (&w)[3][DG_K]
 // grid: (ceil(nj / 63), ceil((i_end - i_begin) / rows_per_wave)), block 64
 // ---------------------------------------------------------------------------------------------
 
-// One face node between two zones whose weights are `a` (this wave's row / this lane) and `b` (the zone on the other
-// side, loaded here from `b_at`).  `swap` false: `a` is the zone ABOVE the face (the face is a's low face `fn`);
-// true: `a` is the zone BELOW it (the face is b's low face `fn`).  fa: the fluxes with the sound speed at (xa, ya),
-// a's own position of the node; fb: with it at (xb, yb), b's -- solved only if `both` and the positions differ.
-__device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a)[3][DG_K], const double *b_at, int fn,
+// The trace of a zone's weights at face-table row fn (and, for the viscous stress, its tangential derivative there).
+__device__ __forceinline__ void dg_traces(const double (&w)[3][DG_K], const double (*tab)[DG_K], const double (*tan)[DG_K],
+                                          int fn, bool viscous, double (&u)[3], double (&t)[3])
+{
+    dg_eval<63>(w, tab[fn], u);
+    if (viscous) dg_eval<63>(w, tan[fn], t);
+}
+
+// One face node between two zones: `a` (this wave's row / this lane, its weights) and `b` (the zone on the other side,
+// given by its trace ub and tangential derivative tb at the node: the caller forms them from b's weights, or takes
+// them from the lane that holds b).  `swap` false: `a` is the zone ABOVE the face (the face is a's low face `fn`, b
+// is seen through its high-end basis dg_tab.face_nb); true: `a` is the zone BELOW it (the face is b's low face `fn`,
+// b is seen through dg_tab.face_own).  fa: the fluxes with the sound speed at (xa, ya), a's own position of the
+// node; fb: with it at (xb, yb), b's -- solved only if `both` and the positions differ.
+__device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a)[3][DG_K], const double (&ub)[3],
+                                             const double (&tb)[3], int fn,
                                              bool ydir, bool swap, bool both, double xa, double ya, double xb, double yb,
                                              const DgRcp &rmach2, const DgRcp &rdx, const DgRcp &rdy,
                                              const double (&mx)[2], const double (&my)[2], const double (&mm)[2],
                                              const double (&mrs)[2], bool viscous, double (&fa)[3], double (&fb)[3])
 {
-    double b[3][DG_K];
-    dg_load(b_at, b);
     const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, xa, ya, mx, my, mm, mrs);
-    // the traces: the zone above the face through its low-end basis, the zone below through its high-end basis
-    const double(*tab_a)[DG_K] = swap ? dg_tab.face_nb : dg_tab.face_own;
-    const double(*tab_b)[DG_K] = swap ? dg_tab.face_own : dg_tab.face_nb;
-    double ua[3], ub[3];
-    dg_eval<63>(a, tab_a[fn], ua);
-    dg_eval<63>(b, tab_b[fn], ub);
+    // a's traces: the zone above the face through its low-end basis, the zone below through its high-end basis
+    double ua[3], ta[3];
+    dg_traces(a, swap ? dg_tab.face_nb : dg_tab.face_own, swap ? dg_tab.face_nb_t : dg_tab.face_own_t, fn, viscous, ua, ta);
     const DgRcp ra = dg_rcp(ua[0]), rb = dg_rcp(ub[0]);
     double up[3], um[3]; // high-side and low-side traces
 #pragma unroll
@@ -363,11 +369,6 @@ __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a
     double h1 = 0.0, h2 = 0.0, l1 = 0.0, l2 = 0.0; // viscous stresses of the high-side and the low-side zone
     if (viscous) {
         // the face-normal "gradient" IS the trace
-        const double(*tan_a)[DG_K] = swap ? dg_tab.face_nb_t : dg_tab.face_own_t;
-        const double(*tan_b)[DG_K] = swap ? dg_tab.face_own_t : dg_tab.face_nb_t;
-        double ta[3], tb[3];
-        dg_eval<63>(a, tan_a[fn], ta);
-        dg_eval<63>(b, tan_b[fn], tb);
         double gxa[3], gya[3], gxb[3], gyb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -417,52 +418,107 @@ __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a
     }
 }
 
-__global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double *__restrict__ weights0,
+__global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const double *__restrict__ weights0,
                                                         const double *__restrict__ weights1,
                                                         double *__restrict__ weights2, double *wavespeed_max)
 {
     // the fluxes through the next row's low x-face as that row sees them: [node][field][lane]
     __shared__ double next_xl[3][3][64];
-    const int lane = threadIdx.x;
-    const int j = blockIdx.x * 63 + lane;
+    // the weights of the wave's 64 zones in the NEXT row and of the zone to their left, as they lie in memory (27
+    // doubles per zone, 14 KB: 27 unit-stride sweeps of the wave and a part of one).  The three x-faces above a row
+    // read the zone above from here, and the next iteration takes it from here as its own.  (Read from memory where
+    // they are used, those were four 216-byte-strided reads of the same bytes, 15-50 us apart -- longer than a line
+    // survives in L2 at this rate: the launch fetched 3.7 x its algorithmic bytes, profiles/r3_dg2048_pmc.txt.)
+    __shared__ double row_up[65 * DG_NW];
+    // lane 0's left neighbour in the CURRENT row (another wave's zone), kept back from row_up before it is restaged
+    __shared__ double left_zone[DG_NW];
+    const int lane0 = threadIdx.x;
+    const int j0 = blockIdx.x * 63;
     const int i_first = P.i_begin + blockIdx.y * P.rows_per_wave;
     const int i_stop = i_first + P.rows_per_wave < P.i_end ? i_first + P.rows_per_wave : P.i_end;
-    const bool present = j <= P.nj;            // solves its low y-face
-    const bool owner = lane < 63 && j < P.nj;  // updates zones
-    const long sj = DG_NW, si = (long)DG_NW * (P.nj + 2);
+    const long si = (long)DG_NW * (P.nj + 2);
     const double dx = P.dx, dy = P.dy;
-    const double mx[2] = {P.m[0].x, P.m[1].x}, my[2] = {P.m[0].y, P.m[1].y};
-    const double mm[2] = {P.m[0].mass, P.m[1].mass}, mrs[2] = {P.m[0].rsoft, P.m[1].rsoft};
     const bool viscous = P.nu > 0.0;
     const DgRcp rdx = dg_rcp(dx), rdy = dg_rcp(dy), rmach2 = dg_rcp(P.mach2), rvol = dg_rcp(P.cell_volume);
     const double dt = P.dt_ptr ? *P.dt_ptr : P.dt;
-    const double yc = P.yl + (j + 0.5) * dy;
-    const double yc_left = P.yl + ((j - 1) + 0.5) * dy; // the left lane's own centre, formed as that lane forms it
-    // an outflow edge's guard zone is a copy of the edge zone itself: the lane beyond the edge (it only provides the
-    // edge zone's high y-face) then IS the edge zone
-    const int ja = (P.clamp_j && j == P.nj) ? j - 1 : j;
+    // the zone left of lane 0's: slot 0 of the staged row (under an outflow clamp at the row's start: its own zone)
+    const int left_slot = (P.clamp_j && j0 == 0) ? 1 : 0;
+    // the staged segment: memory columns j0 ... j0 + 64 of a row (zones j0 - 1 ... j0 + 63), as far as the row, its
+    // high guard column included, goes; addresses past it are clamped to its last double
+    const int nstage = (P.nj + 2 - j0 < 65 ? P.nj + 2 - j0 : 65) * DG_NW;
+    auto stage_row = [&](int row, int lane_) {
+        const double *seg = weights1 + (long)(row + 1) * si + (long)j0 * DG_NW;
+        double staged[DG_NW], tail = 0.0;
+        if (nstage == 65 * DG_NW) { // (wave-uniform: every wave but the last of a row)
+#pragma unroll
+            for (int r = 0; r < DG_NW; ++r) staged[r] = (seg + 64 * r)[lane_]; // (scalar base + lane: no address registers)
+            if (lane_ < DG_NW) tail = (seg + 64 * DG_NW)[lane_];
+        } else {
+            // (the bound is made opaque here: as a loop invariant the 27 clamped indices are formed once, ahead of the
+            // row loop, and live in scratch memory from then on)
+            unsigned last = nstage - 1, first = lane_;
+            asm volatile("" : "+v"(last), "+v"(first));
+#pragma unroll
+            for (int r = 0; r < DG_NW; ++r) {
+                const unsigned k = first + 64 * r;
+                staged[r] = seg[k < last ? k : last];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DG_NW; ++r) row_up[lane_ + 64 * r] = staged[r];
+        if (lane_ < DG_NW) row_up[lane_ + 64 * DG_NW] = tail; // (zone j0 + 63: lane 63's, which is needed only when full)
+    };
     double speed = 0.0;
 
-    if (present) {
+    if (i_first < i_stop) stage_row(i_first, lane0);
 #pragma unroll 1
-        for (int i = i_first; i < i_stop; ++i) {
-            const long at = (long)(i + 1) * si + (ja + 1) * sj;
-            double cc[3][DG_K];
-            dg_load(weights1 + at, cc);
+    for (int i = i_first; i < i_stop; ++i) {
+        // What depends on the lane alone is formed again in every row, from a copy of the lane index that the
+        // compiler cannot see through: as loop invariants those values (and everything the node loops derive from
+        // them) are formed once ahead of the row loop, and at 2 waves per SIMD they then live in scratch memory.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int j = j0 + lane;
+        const bool present = j <= P.nj;            // solves its low y-face
+        const bool owner = lane < 63 && j < P.nj;  // updates zones
+        const double yc = P.yl + (j + 0.5) * dy;
+        const double yc_left = P.yl + ((j - 1) + 0.5) * dy; // the left lane's own centre, formed as that lane forms it
+        // an outflow edge's guard zone is a copy of the edge zone itself: the lane beyond the edge (it only provides
+        // the edge zone's high y-face) then IS the edge zone.  (Lanes beyond the row's last column, in the last wave
+        // of a row only, go through the face nodes of that column: nothing of theirs is used.)
+        const int ja = (P.clamp_j && j == P.nj) ? j - 1 : (present ? j : P.nj);
+        const unsigned zoff = (ja + 1) * DG_NW;                 // this lane's zone within a row of the arrays
+        const double *mine_up = row_up + (ja - j0 + 1) * DG_NW; // ... and within the staged row
+        double cc[3][DG_K];
+        dg_load(mine_up, cc);
+        if (lane < DG_NW) left_zone[lane] = row_up[left_slot * DG_NW + lane];
+        // the next row (above the domain's last row under an outflow clamp: the row itself).  One wave, and LDS
+        // accesses of a wave complete in program order: the reads above come before these writes.
+        stage_row((P.clamp_hi && i == P.ni - 1) ? i : i + 1, lane);
+        {
             const double xc = P.xl + (i + 0.5) * dx;
             const double xc_up = P.xl + ((i + 1) + 0.5) * dx; // the next row's own centre, formed as that row forms it
-            // the zones on the other side of the faces that are solved here
-            const long below_x = (P.clamp_lo && i == 0) ? at : at - si;
-            const long above_x = (P.clamp_hi && i == P.ni - 1) ? at : at + si;
-            const long left_y = (P.clamp_j && j == 0) ? at : (long)(i + 1) * si + j * sj; // (column j is zone j - 1)
+            // the row below is read from memory (in the first row of a march only)
+            const double *row_below = weights1 + (long)((P.clamp_lo && i == 0) ? i + 1 : i) * si;
 
             // ---- surface integral, :848-961: per Gauss node the faces xl, xr, yl, yr ----------
+            // The parameters of each phase of a row are read from the kernel's argument block at the start of that
+            // phase, through a pointer the compiler cannot see through: as values of the whole kernel the ~100 of
+            // them would all occupy scalar registers across both node loops, and those that do not fit are kept in
+            // lanes of a vector register (one v_readlane per use: 13 % of the loops' instructions).
+            const __attribute__((address_space(4))) DgParams *pf =
+                (const __attribute__((address_space(4))) DgParams *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(pf));
+            const DgParams &Pf = *(const DgParams *)pf;
             double srf[3][DG_K]; // equation_20
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
                 for (int k = 0; k < DG_K; ++k) srf[q][k] = 0.0;
             double yr[3] = {0.0, 0.0, 0.0};
+            {
+            const double mx[2] = {Pf.m[0].x, Pf.m[1].x}, my[2] = {Pf.m[0].y, Pf.m[1].y};
+            const double mm[2] = {Pf.m[0].mass, Pf.m[1].mass}, mrs[2] = {Pf.m[0].rsoft, Pf.m[1].rsoft};
 #pragma unroll 1
             for (int fn = 0; fn < 12; ++fn) {
                 const int face = fn & 3, q = fn >> 2;
@@ -477,13 +533,19 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                 } else {
                     const double x = xc + dg_tab.face_cx[fn] * dx; // the node as this zone places it
                     const double y = yc + dg_tab.face_cy[fn] * dy;
-                    double fother[3];
+                    double fother[3], nb[3][DG_K], ub[3], tb[3];
                     if (face == 1) {
+                        // the zone above, from the staged row (through an offset the compiler cannot see through:
+                        // hoisted out of the node loop, its 18 doubles would stay in registers across it)
+                        int up_at = (ja - j0 + 1) * DG_NW;
+                        asm volatile("" : "+v"(up_at));
+                        dg_load(row_up + up_at, nb);
                         // as the next row's low x-face: its table row, its position of the node
                         const int fu = q * 4;
                         const double xu = xc_up + dg_tab.face_cx[fu] * dx;
                         const double yu = yc + dg_tab.face_cy[fu] * dy;
-                        dg_face_node(P, cc, weights1 + above_x, fu, false, true, i + 1 < i_stop, x, y, xu, yu, rmach2, rdx, rdy,
+                        dg_traces(nb, dg_tab.face_own, dg_tab.face_own_t, fu, viscous, ub, tb);
+                        dg_face_node(Pf, cc, ub, tb, fu, false, true, i + 1 < i_stop, x, y, xu, yu, rmach2, rdx, rdy,
                                      mx, my, mm, mrs, viscous, fhat, fother);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) next_xl[q][c][lane] = fother[c];
@@ -491,12 +553,30 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                         // the left lane sees this face as its high y-face fn + 1
                         const double xl_ = xc + dg_tab.face_cx[fn + 1] * dx;
                         const double yl_ = yc_left + dg_tab.face_cy[fn + 1] * dy;
-                        dg_face_node(P, cc, weights1 + left_y, fn, true, false, true, x, y, xl_, yl_, rmach2, rdx, rdy, mx, my, mm,
+                        // the zone to the left is the lane below's: every lane forms ITS zone's high-end trace (the
+                        // same operations on the same weights as forming it here from that zone's weights) and
+                        // hands it up one lane; lane 0's left zone is another wave's, read from memory
+                        double uh[3], th[3] = {0.0, 0.0, 0.0};
+                        dg_traces(cc, dg_tab.face_nb, dg_tab.face_nb_t, fn, viscous, uh, th);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            ub[c] = from_lane_below(uh[c]);
+                            tb[c] = from_lane_below(th[c]);
+                        }
+                        if (lane == 0) {
+                            int left_at = 0;
+                            asm volatile("" : "+v"(left_at));
+                            dg_load(left_zone + left_at, nb);
+                            dg_traces(nb, dg_tab.face_nb, dg_tab.face_nb_t, fn, viscous, ub, tb);
+                        }
+                        dg_face_node(Pf, cc, ub, tb, fn, true, false, true, x, y, xl_, yl_, rmach2, rdx, rdy, mx, my, mm,
                                      mrs, viscous, fhat, fother);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) yr[c] = from_lane_above(fother[c]); // the high y-face of THIS lane's zone
                     } else {
-                        dg_face_node(P, cc, weights1 + below_x, fn, false, false, false, x, y, x, y, rmach2, rdx, rdy, mx, my, mm,
+                        dg_load(row_below + zoff, nb);
+                        dg_traces(nb, dg_tab.face_nb, dg_tab.face_nb_t, fn, viscous, ub, tb);
+                        dg_face_node(Pf, cc, ub, tb, fn, false, false, false, x, y, x, y, rmach2, rdx, rdy, mx, my, mm,
                                      mrs, viscous, fhat, fother);
                     }
                 }
@@ -511,8 +591,15 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                     }
                 }
             }
+            }
             if (!owner) continue;
 
+            const __attribute__((address_space(4))) DgParams *pv =
+                (const __attribute__((address_space(4))) DgParams *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(pv));
+            const DgParams &Pv = *(const DgParams *)pv;
+            const double mx[2] = {Pv.m[0].x, Pv.m[1].x}, my[2] = {Pv.m[0].y, Pv.m[1].y};
+            const double mm[2] = {Pv.m[0].mass, Pv.m[1].mass}, mrs[2] = {Pv.m[0].rsoft, Pv.m[1].rsoft};
             // ---- volume integral and sources, :776-844 ---------------------------------------
             double vol[3][DG_K], src[3][DG_K]; // equation_19, source_weights
 #pragma unroll
@@ -524,18 +611,18 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                 const double x = xc + dg_tab.vol_cx[nd] * dx;
                 const double y = yc + dg_tab.vol_cy[nd] * dy;
                 const double gw = dg_tab.vol_gw[nd];
-                const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, x, y, mx, my, mm, mrs);
+                const double cs2 = dg_cs2(Pv.cs2, rmach2, Pv.eos, x, y, mx, my, mm, mrs);
                 double u[3], p[3], fx[3], fy[3];
                 dg_eval<63>(cc, dg_tab.vol_phi[nd], u);
                 const DgRcp ru = dg_rcp(u[0]);
-                dg_c2p(u, ru, p, P.vmax);
+                dg_c2p(u, ru, p, Pv.vmax);
                 dg_flux(p, u, cs2, p[1], 1.0, 0.0, fx);
                 dg_flux(p, u, cs2, p[2], 0.0, 1.0, fy);
                 if (viscous) {
                     double ux[3], uy[3], txx, txy, tyy;
                     dg_eval<0x38>(cc, dg_tab.vol_dpx[nd], ux); // m >= 1: slots 3, 4, 5
                     dg_eval<0x16>(cc, dg_tab.vol_dpy[nd], uy); // n >= 1: slots 1, 2, 4
-                    dg_stress(u, ru, ux, uy, P.nu, rdx, rdy, txx, txy, tyy);
+                    dg_stress(u, ru, ux, uy, Pv.nu, rdx, rdy, txx, txy, tyy);
                     fx[1] -= txx;
                     fx[2] -= txy;
                     fy[1] -= txy;
@@ -551,8 +638,8 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                 }
                 double du[3] = {0.0, 0.0, 0.0};
                 dg_buffer_source(P, x, y, dt, u, du);
-                dg_mass_source(P.m[0], x, y, dt, p, du);
-                dg_mass_source(P.m[1], x, y, dt, p, du);
+                dg_mass_source(Pv.m[0], x, y, dt, p, du);
+                dg_mass_source(Pv.m[1], x, y, dt, p, du);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -561,8 +648,8 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
             }
 
             // ---- :963-981 -------------------------------------------------------------------------
-            const double *w0 = weights0 + at;
-            double *w2 = weights2 + at;
+            const double *w0 = weights0 + (long)(i + 1) * si + zoff; // (scalar row base + this lane's 32-bit offset)
+            double *w2 = weights2 + (long)(i + 1) * si + zoff;
             double avg[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -570,16 +657,16 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
                 for (int k = 0; k < DG_K; ++k) {
                     const int s = q * 9 + DG_SLOT[k];
                     double wn = cc[q][k] + dg_div((vol[q][k] - srf[q][k]) * 0.5 * dt, rvol) + src[q][k];
-                    wn = (1.0 - P.rk) * wn + P.rk * w0[s];
+                    wn = (1.0 - Pv.rk) * wn + Pv.rk * w0[s];
                     w2[s] = wn;
                     if (k == 0) avg[q] = wn;
                 }
             }
 
-            if (P.want_ws) { // cbdisodg_2d_wavespeed (:1152-1175) of the zone just written
+            if (Pv.want_ws) { // cbdisodg_2d_wavespeed (:1152-1175) of the zone just written
                 double pa[3];
-                dg_c2p(avg, dg_rcp(avg[0]), pa, P.vmax);
-                double cs2 = dg_cs2(P.cs2, rmach2, P.eos, xc, yc, P.wx, P.wy, P.wm, P.wrs);
+                dg_c2p(avg, dg_rcp(avg[0]), pa, Pv.vmax);
+                double cs2 = dg_cs2(Pv.cs2, rmach2, Pv.eos, xc, yc, Pv.wx, Pv.wy, Pv.wm, Pv.wrs);
                 speed = max_nan(speed, max_speed(pa[1], pa[2], cs2));
             }
         }
@@ -587,7 +674,7 @@ __global__ __launch_bounds__(64) void dg_advance_kernel(DgParams P, const double
     if (P.want_ws) {
         speed = wave_max_nonneg(speed);
         // a plain load first skips the same-address atomic for every wave that cannot raise the maximum any more
-        if (lane == 0 && !(speed <= *(volatile double *)wavespeed_max)) atomic_max_nonneg(wavespeed_max, speed);
+        if (lane0 == 0 && !(speed <= *(volatile double *)wavespeed_max)) atomic_max_nonneg(wavespeed_max, speed);
     }
 }
 
