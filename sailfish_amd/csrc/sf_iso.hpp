@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256, (WS == 0 && !UN) ? SFHIP_ISO_A0_WAVES : 3) voi
         const double eb[4] = {ebp[0], ebp[1], ebp[2], ebp[3]};
         const double ea[5] = {0.0, 0.0, eap[2], eap[3], eap[4]};
         const bool upd = r - 2 >= I0;
+#if defined(SFHIP_DIAG_PRIO)  // diagnosis builds only: the wave's issue priority raised while it issues its memory requests
+        __builtin_amdgcn_s_setprio(SFHIP_DIAG_PRIO);
+#endif
         if (upd && want_un) {
             // u^n of the row updated in this iteration: in flight during both face blocks
             const double *us = unsrc + (long)(r - 2) * si + ucol;
@@ -476,6 +479,10 @@ __global__ __launch_bounds__(256, (WS == 0 && !UN) ? SFHIP_ISO_A0_WAVES : 3) voi
 #endif
         }
         __builtin_amdgcn_sched_barrier(0); // keep the requests first (the scheduler would sink them by ~150 instructions)
+#if defined(SFHIP_DIAG_PRIO)
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #if defined(SFHIP_DIAG_NO_COMPUTE) && defined(SFHIP_DIAG_TWO_ROWS)  // the same traffic, two rows' requests in flight per wave
         {
             if ((r - I0) & 1) continue;
@@ -617,6 +624,9 @@ __global__ __launch_bounds__(256, (WS == 0 && !UN) ? SFHIP_ISO_A0_WAVES : 3) voi
         iso_row_leaves(pb, gxb, sxx, sxy, quarter, pmx, txx, txy);
         enter(pn);
         __builtin_amdgcn_sched_barrier(0); // the requested row is in use above this line, stores go below
+#if defined(SFHIP_DIAG_PRIO) && defined(SFHIP_DIAG_PRIO_STORES)
+        __builtin_amdgcn_s_setprio(SFHIP_DIAG_PRIO);
+#endif
 #if defined(SFHIP_DIAG_STORE_EVERY)  // diagnosis builds only (WRONG results): the same bytes, stored every Nth iteration
         if (upd && store_lane && (r % SFHIP_DIAG_STORE_EVERY) == 0) {
             for (int k = 0; k < SFHIP_DIAG_STORE_EVERY; ++k) {
