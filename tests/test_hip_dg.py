@@ -129,7 +129,11 @@ def test_dg_clamped_rows_and_epilogue(kw, orc, hip_lib):
 @pytest.mark.parametrize("kw", [dict(ni=21, nj=130, extent=(-1.7, 1.3, -2.1, 2.9)),
                                 dict(ni=9, nj=63, extent=(-1.0, 2.0, -0.7, 0.9), nu=0.01, rk_param=0.5),
                                 dict(ni=6, nj=64, eos=1, extent=(-1.1, 1.1, -1.3, 1.3)),
-                                dict(ni=33, nj=200, extent=(-2.0, 2.0, -2.0, 2.0), sink_model=1)], ids=IDS)
+                                dict(ni=33, nj=200, extent=(-2.0, 2.0, -2.0, 2.0), sink_model=1),
+                                # a wave stages 65 zones of a row at once: a row that ends one zone short of that, and
+                                # one whose last wave's 65 zones end exactly at the row's end
+                                dict(ni=7, nj=62, extent=(-1.3, 1.1, -0.9, 1.9), nu=0.01),
+                                dict(ni=8, nj=126, extent=(-1.9, 1.4, -1.2, 2.3), rk_param=0.5)], ids=IDS)
 @pytest.mark.parametrize("clamped", [False, True], ids=["guards", "clamped"])
 @pytest.mark.parametrize("rows_per_wave", [1, 3, 8])
 def test_dg_faces_solved_once_equal_faces_solved_twice(kw, clamped, rows_per_wave, hip_lib, monkeypatch):
