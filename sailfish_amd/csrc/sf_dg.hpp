@@ -320,7 +320,12 @@ __device__ __forceinline__ void dg_load(const double *zone, double (&w)[3][DG_K]
 //   yl  between the lane to the left and this lane: as this lane sees them, and as the left lane sees them as its
 //       yr, which that lane fetches with one lane shift per component;
 //   xl  only in the first row of the march (the row below belongs to another wave, which solves that face again).
-// 12 -> 6 + 3 / rows_per_wave face nodes per zone; every wave is its own workgroup, no barrier, 4.6 KB of LDS.
+// 12 -> 6 + 3 / rows_per_wave face nodes per zone; every wave is its own workgroup, no barrier.
+// Memory: the wave reads a row ONCE, with unit-stride sweeps, into 14 KB of LDS one iteration before the row is its
+// own (the zone above the three xr nodes and the row's own weights come from there); the left zone's trace at a yl
+// node comes from the lane below (lane 0 forms it from the staged copy of the zone left of the wave).  19 KB of LDS
+// per wave, 8 waves per CU.  The parameters of a row's two phases (face loop, volume loop + update) are read from
+// the kernel-argument block at the start of each phase (DESIGN.md section 9 says why).
 // (A tile of 4 rows x 63 columns with one wave per row and the x-faces exchanged through LDS behind a barrier was
 // built first: 6.75 face nodes per zone, 24 % fewer instructions, but 10 % less time only -- the barrier and the
 // waves that solve the tile's upper edge cost 6 % and 8 %.)
