@@ -375,6 +375,10 @@ __global__ __launch_bounds__(256) void srhd_advance_kernel(SrhdParams P, const d
 #if !defined(SFHIP_SRHD_WAVES)
 #define SFHIP_SRHD_WAVES 2
 #endif
+// FO: the run has first-order zones (num_first_order_zones > 0).  Without them the tests on the viewing zone's index
+//     (uniform per row, but selects on every slope and state all the same) and the second view of one row of faces
+//     drop out of the march: the same operations on the same operands, so the same bits.
+template <bool FO>
 __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdParams P, const double *__restrict__ cons_rk,
                                                             const double *__restrict__ prim_rd,
                                                             const double *__restrict__ cons_rd,
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
     const double dcosq = c1 - c0, dsinq = s1 - s0;
     const double sfac = P.a0 + P.adot * P.time;
     const bool jet_on = P.jet_mdot > 0.0;
-    const int nfo = P.num_first_order_zones;
+    const int nfo = FO ? P.num_first_order_zones : 0;
 
     // zone rows [i0, i1) of this chunk; array rows are zone rows + NG
     const int i0 = chunk * rows_per_chunk;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
         __builtin_amdgcn_sched_barrier(0);
         // y-slopes of row r (neighbouring lanes hold the clamped neighbours)
         double gyc[4];
-        const bool so_c = r >= nfo;
+        const bool so_c = !FO || r >= nfo;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double g = sr_slope(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]), P.theta);
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
         }
         if (r >= i0) {
             const int ib = r - 1;       // zone row of pb
-            const bool so_b = ib >= nfo;
+            const bool so_b = !FO || ib >= nfo;
             double gxb[4];              // x-slopes of row r-1, not zeroed
 #pragma unroll
             for (int q = 0; q < 4; ++q) gxb[q] = sr_slope(pa[q], pb[q], pc[q], P.theta);
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
                     pr[q] = pb[q] - 0.5 * (so_b ? gxb[q] : 0.0);
                 }
                 sr_hllc<1>(pl, pr, xlo * P.adot, Flo);
-                if (ib == nfo && ib > 0) {
+                if (FO && ib == nfo && ib > 0) {
                     // row r-2 < nfo looks at this face without slopes (p +- 0.5 * 0, literally)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

@@ -1763,7 +1763,11 @@ static int srhd_advance_impl(int ni, int nj, double *face_positions, double *con
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-    hipLaunchKernelGGL(sf::srhd_march_kernel, grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
+    if (P.num_first_order_zones > 0)
+        hipLaunchKernelGGL((sf::srhd_march_kernel<true>), grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
+                       conserved_wr, rows_per_chunk, nstrips, nchunks);
+    else
+        hipLaunchKernelGGL((sf::srhd_march_kernel<false>), grid, block, 0, t_stream, P, conserved_rk, primitive_rd, conserved_rd,
                        conserved_wr, rows_per_chunk, nstrips, nchunks);
     return check_launch("srhd_2d_advance_rk");
 }
