@@ -151,16 +151,18 @@ __device__ __forceinline__ double dg_div(double num, const DgRcp &d) { return ex
 // ---------------------------------------------------------------------------------------------
 
 // gravitational_potential + sound_speed_squared, :56-81, :171-188; masses given as 4 arrays
+// (LOCISO: locally isothermal with both masses positive, established on the host)
+template <bool LOCISO = false>
 __device__ __forceinline__ double dg_cs2(double cs2, const DgRcp &mach2, int eos, double x, double y,
                                          const double (&mx)[2], const double (&my)[2], const double (&mm)[2],
                                          const double (&mrs)[2])
 {
-    if (eos == 1) return cs2;
-    if (eos != 2) return 1.0;
+    if (!LOCISO && eos == 1) return cs2;
+    if (!LOCISO && eos != 2) return 1.0;
     double phi = 0.0;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        if (mm[p] > 0.0) {
+        if (LOCISO || mm[p] > 0.0) {
             double ddx = x - mx[p];
             double ddy = y - my[p];
             double r2 = ddx * ddx + ddy * ddy;
@@ -347,6 +349,7 @@ __device__ __forceinline__ void dg_traces(const double (&w)[3][DG_K], const doub
 // is seen through its high-end basis dg_tab.face_nb); true: `a` is the zone BELOW it (the face is b's low face `fn`,
 // b is seen through dg_tab.face_own).  fa: the fluxes with the sound speed at (xa, ya), a's own position of the
 // node; fb: with it at (xb, yb), b's -- solved only if `both` and the positions differ.
+template <bool LOCISO>
 __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a)[3][DG_K], const double (&ub)[3],
                                              const double (&tb)[3], int fn,
                                              bool ydir, bool swap, bool both, double xa, double ya, double xb, double yb,
@@ -354,7 +357,7 @@ __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a
                                              const double (&mx)[2], const double (&my)[2], const double (&mm)[2],
                                              const double (&mrs)[2], bool viscous, double (&fa)[3], double (&fb)[3])
 {
-    const double cs2 = dg_cs2(P.cs2, rmach2, P.eos, xa, ya, mx, my, mm, mrs);
+    const double cs2 = dg_cs2<LOCISO>(P.cs2, rmach2, P.eos, xa, ya, mx, my, mm, mrs);
     // a's traces: the zone above the face through its low-end basis, the zone below through its high-end basis
     double ua[3], ta[3];
     dg_traces(a, swap ? dg_tab.face_nb : dg_tab.face_own, swap ? dg_tab.face_nb_t : dg_tab.face_own_t, fn, viscous, ua, ta);
@@ -412,10 +415,10 @@ __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a
     solve(cs2, fa);
     bool differs = false;
 #if !defined(SFHIP_DIAG_DG_ONE_VIEW)  // diagnosis builds only (WRONG in the last place): checks that the tests see the second view
-    if (both && P.eos == 2) differs = xb != xa || yb != ya;
+    if (both && (LOCISO || P.eos == 2)) differs = xb != xa || yb != ya;
 #endif
     if (__builtin_amdgcn_ballot_w64(differs) != 0) { // (wave-uniform)
-        const double cs2b = dg_cs2(P.cs2, rmach2, P.eos, xb, yb, mx, my, mm, mrs);
+        const double cs2b = dg_cs2<LOCISO>(P.cs2, rmach2, P.eos, xb, yb, mx, my, mm, mrs);
         solve(cs2b, fb);
     } else {
 #pragma unroll
@@ -423,6 +426,9 @@ __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a
     }
 }
 
+// VISC: nu > 0; LOCISO: locally isothermal gas, both masses positive -- established on the host (the uniform tests on
+// them, in every node of both loops, drop out).
+template <bool VISC, bool LOCISO>
 __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const double *__restrict__ weights0,
                                                         const double *__restrict__ weights1,
                                                         double *__restrict__ weights2, double *wavespeed_max)
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
     const int i_stop = i_first + P.rows_per_wave < P.i_end ? i_first + P.rows_per_wave : P.i_end;
     const long si = (long)DG_NW * (P.nj + 2);
     const double dx = P.dx, dy = P.dy;
-    const bool viscous = P.nu > 0.0;
+    const bool viscous = VISC;
     const DgRcp rdx = dg_rcp(dx), rdy = dg_rcp(dy), rmach2 = dg_rcp(P.mach2), rvol = dg_rcp(P.cell_volume);
     const double dt = P.dt_ptr ? *P.dt_ptr : P.dt;
     // the zone left of lane 0's: slot 0 of the staged row (under an outflow clamp at the row's start: its own zone)
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
                         const double xu = xc_up + dg_tab.face_cx[fu] * dx;
                         const double yu = yc + dg_tab.face_cy[fu] * dy;
                         dg_traces(nb, dg_tab.face_own, dg_tab.face_own_t, fu, viscous, ub, tb);
-                        dg_face_node(Pf, cc, ub, tb, fu, false, true, i + 1 < i_stop, x, y, xu, yu, rmach2, rdx, rdy,
+                        dg_face_node<LOCISO>(Pf, cc, ub, tb, fu, false, true, i + 1 < i_stop, x, y, xu, yu, rmach2, rdx, rdy,
                                      mx, my, mm, mrs, viscous, fhat, fother);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) next_xl[q][c][lane] = fother[c];
@@ -574,14 +580,14 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
                             dg_load(left_zone + left_at, nb);
                             dg_traces(nb, dg_tab.face_nb, dg_tab.face_nb_t, fn, viscous, ub, tb);
                         }
-                        dg_face_node(Pf, cc, ub, tb, fn, true, false, true, x, y, xl_, yl_, rmach2, rdx, rdy, mx, my, mm,
+                        dg_face_node<LOCISO>(Pf, cc, ub, tb, fn, true, false, true, x, y, xl_, yl_, rmach2, rdx, rdy, mx, my, mm,
                                      mrs, viscous, fhat, fother);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) yr[c] = from_lane_above(fother[c]); // the high y-face of THIS lane's zone
                     } else {
                         dg_load(row_below + zoff, nb);
                         dg_traces(nb, dg_tab.face_nb, dg_tab.face_nb_t, fn, viscous, ub, tb);
-                        dg_face_node(Pf, cc, ub, tb, fn, false, false, false, x, y, x, y, rmach2, rdx, rdy, mx, my, mm,
+                        dg_face_node<LOCISO>(Pf, cc, ub, tb, fn, false, false, false, x, y, x, y, rmach2, rdx, rdy, mx, my, mm,
                                      mrs, viscous, fhat, fother);
                     }
                 }
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
                 const double x = xc + dg_tab.vol_cx[nd] * dx;
                 const double y = yc + dg_tab.vol_cy[nd] * dy;
                 const double gw = dg_tab.vol_gw[nd];
-                const double cs2 = dg_cs2(Pv.cs2, rmach2, Pv.eos, x, y, mx, my, mm, mrs);
+                const double cs2 = dg_cs2<LOCISO>(Pv.cs2, rmach2, Pv.eos, x, y, mx, my, mm, mrs);
                 double u[3], p[3], fx[3], fy[3];
                 dg_eval<63>(cc, dg_tab.vol_phi[nd], u);
                 const DgRcp ru = dg_rcp(u[0]);

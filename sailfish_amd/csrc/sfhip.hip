@@ -1895,7 +1895,11 @@ int dg_stage_impl(
     }
     P.rows_per_wave = rpw;
     dim3 block(64), grid(nstrips, (nrows + rpw - 1) / rpw);
-    hipLaunchKernelGGL(sf::dg_advance_kernel, grid, block, 0, t_stream, P, weights0, weights1, weights2, wavespeed_max);
+    // instantiations by what the host knows of the physics: viscosity on; locally isothermal gas with both masses positive
+    const bool visc = P.nu > 0.0, lociso = P.eos == 2 && P.m[0].mass > 0.0 && P.m[1].mass > 0.0;
+    auto kernel = visc ? (lociso ? sf::dg_advance_kernel<true, true> : sf::dg_advance_kernel<true, false>)
+                       : (lociso ? sf::dg_advance_kernel<false, true> : sf::dg_advance_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, grid, block, 0, t_stream, P, weights0, weights1, weights2, wavespeed_max);
     return check_launch(who);
 }
 
