@@ -214,7 +214,8 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     P.reverse = P.un_mode != 0 && reverse_later_stages();
     // the full-physics instantiations (see gam_stage_kernel): same formulas, flag tests resolved here
     auto active = [](const sf::Mass &m) { return m.mass > 0.0 && m.sink_model >= 1 && m.sink_model <= 3; };
-    const bool full = P.alpha > 0.0 && active(P.m[0]) && active(P.m[1]) && P.buf_on && !env_int("SFHIP_GENERIC_STAGE", 0);
+    const bool full = P.alpha > 0.0 && active(P.m[0]) && active(P.m[1]) && P.buf_on && P.constant_softening &&
+                      P.cooling == 0.0 && !env_int("SFHIP_GENERIC_STAGE", 0);
     using Kernel = void (*)(sf::GamParams, const double *, const double *, double *, double *, int, int);
     static const Kernel table[2][2][2] = {
         {{sf::gam_stage_kernel<false, false, false>, sf::gam_stage_kernel<false, false, true>},
