@@ -375,6 +375,8 @@ __global__ __launch_bounds__(256) void srhd_advance_kernel(SrhdParams P, const d
 #if !defined(SFHIP_SRHD_WAVES)
 #define SFHIP_SRHD_WAVES 2
 #endif
+template <bool V> struct SrTag { static constexpr bool value = V; };
+
 // FO: the run has first-order zones (num_first_order_zones > 0).  Without them the tests on the viewing zone's index
 //     (uniform per row, but selects on every slope and state all the same) and the second view of one row of faces
 //     drop out of the march: the same operations on the same operands, so the same bits.
@@ -427,10 +429,16 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
     }
     // r = zone row whose primitives arrive this iteration; row r-1 gets its x-slopes and faces,
     // row r-2 is updated
-    for (int r = i0 - 2; r <= i1 + 1; ++r) {
+    // One body for every row; STEADY (a tag type) marks the iterations in which all of its row tests are known to
+    // be true -- rows i0 + 2 ... i1 of the chunk -- so that they drop out there: the two Riemann problems of an
+    // iteration (x-face and polar face, independent of each other, each a long chain of IEEE divisions and square
+    // roots) and the update then lie in one scheduling region and interleave.  Contraction is off and every
+    // operation is IEEE: the two instantiations of the body give the same bits.
+    auto body = [&](const int r, auto steady_tag) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
 #pragma unroll
         for (int q = 0; q < 4; ++q) pc[q] = pn[q];
-        if (r < i1 + 1) {
+        if (STEADY || r < i1 + 1) {
             const double *src = prim_rd + (long)(r + 1 + NG) * si + col;
             pn[0] = src[0]; pn[1] = src[1]; pn[2] = src[2]; pn[3] = src[3];
         }
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
             double g = sr_slope(from_lane_below(pc[q]), pc[q], from_lane_above(pc[q]), P.theta);
             gyc[q] = so_c ? g : 0.0;
         }
-        if (r >= i0) {
+        if (STEADY || r >= i0) {
             const int ib = r - 1;       // zone row of pb
             const bool so_b = !FO || ib >= nfo;
             double gxb[4];              // x-slopes of row r-1, not zeroed
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
             const double rlo = xlo * sfac;
             double Fup[4] = {0, 0, 0, 0};   // face between rows r-2 and r-1 as row r-2 sees it (its upper face)
             double Flo[4] = {0, 0, 0, 0};   // ... as row r-1 sees it (its lower face)
-            if (r >= i0 + 1) {
+            if (STEADY || r >= i0 + 1) {
                 // The left state uses row r-2's slopes, the right state row r-1's; whether they count is
                 // decided by the viewing zone (see header).  The two views differ only when ib == nfo.
                 double pl[4], pr[4];
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
                 }
             }
             double GL[4] = {0, 0, 0, 0}, GU[4] = {0, 0, 0, 0};
-            if (ib >= i0 && ib < i1) {
+            if (STEADY || (ib >= i0 && ib < i1)) {
                 // polar face below this lane's zone in row r-1; radii of the row
                 const double rhi = P.faces[ib + 1] * sfac;
                 double pl[4], pr[4], G[4];
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
                 }
             }
             const int iu = r - 2;       // zone row updated now (pa)
-            if (iu >= i0) {
+            if (STEADY || iu >= i0) {
                 const double x0 = P.faces[iu], x1 = P.faces[iu + 1];
                 const double r0 = x0 * sfac, r1 = x1 * sfac;
                 const long c = (long)(iu + NG) * si + (long)J * 4;
@@ -564,7 +572,13 @@ __global__ __launch_bounds__(256, SFHIP_SRHD_WAVES) void srhd_march_kernel(SrhdP
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { gyb[q] = gyc[q]; pa[q] = pb[q]; pb[q] = pc[q]; }
-    }
+    };
+    int r = i0 - 2;
+    for (; r <= i1 + 1 && r < i0 + 2; ++r) body(r, SrTag<false>{});   // the window fills
+#if !defined(SFHIP_SRHD_ONE_BODY)
+    for (; r <= i1; ++r) body(r, SrTag<true>{});
+#endif
+    for (; r <= i1 + 1; ++r) body(r, SrTag<false>{});                   // the last row's update
 }
 
 } // namespace sf
