@@ -426,6 +426,8 @@ __device__ __forceinline__ void dg_face_node(const DgParams &P, const double (&a
     }
 }
 
+template <int F> struct DgFace { static constexpr int value = F; };
+
 // VISC: nu > 0; LOCISO: locally isothermal gas, both masses positive -- established on the host (the uniform tests on
 // them, in every node of both loops, drop out).
 template <bool VISC, bool LOCISO>
@@ -531,9 +533,12 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
             const double mx[2] = {Pf.m[0].x, Pf.m[1].x}, my[2] = {Pf.m[0].y, Pf.m[1].y};
             const double mm[2] = {Pf.m[0].mass, Pf.m[1].mass}, mrs[2] = {Pf.m[0].rsoft, Pf.m[1].rsoft};
 #pragma unroll 1
-            for (int fn = 0; fn < 12; ++fn) {
-                const int face = fn & 3, q = fn >> 2;
-                const bool high = face & 1, ydir = face >> 1;
+            for (int q = 0; q < 3; ++q) {
+            // (the four faces of a Gauss node as straight-line code: the face index is a compile-time constant in each)
+            auto face_step = [&](auto face_tag) __attribute__((always_inline)) {
+                constexpr int face = decltype(face_tag)::value;
+                const int fn = q * 4 + face;
+                constexpr bool high = face & 1, ydir = face >> 1;
                 double fhat[3];
                 if (face == 3) {
 #pragma unroll
@@ -601,6 +606,11 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
                         srf[c][k] += high ? term : -term;
                     }
                 }
+            };
+            face_step(DgFace<0>{});
+            face_step(DgFace<1>{});
+            face_step(DgFace<2>{});
+            face_step(DgFace<3>{});
             }
             }
             if (!owner) continue;
