@@ -302,6 +302,64 @@ __device__ __forceinline__ void gam_mass_source_fast(const Mass &m, double near2
     }
 }
 
+// Both point masses with constant softening (the full-physics instantiation): the same operations in the same order
+// on u as two calls of gam_mass_source_fast, arranged so that the two gravity terms -- a reciprocal square root and
+// its refinement each -- are formed side by side, ahead of the (divergent, rarely taken) sink blocks, of which there
+// is one per mass instead of three.
+__device__ __forceinline__ void gam_two_masses_fast(const Mass *m, const double *near2, const Mass *cold, double ddx0,
+                                                    double ddx1, double ddy0, double ddy1, double dt, const double *prim,
+                                                    double eps, double *u)
+{
+#pragma clang fp contract(fast)
+    const double sigma = prim[0], vx = prim[1], vy = prim[2];
+    const double ddx[2] = {ddx0, ddx1}, ddy[2] = {ddy0, ddy1};
+    double r2[2], fx[2], fy[2], work[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        r2[k] = ddx[k] * ddx[k] + ddy[k] * ddy[k];
+        double r_soft = m[k].rsoft;
+        double y = fast_rsqrt(r2[k] + r_soft * r_soft);
+        double fnum = sigma * m[k].mass * (y * y * y);
+        fx[k] = -fnum * ddx[k];
+        fy[k] = -fnum * ddy[k];
+        work[k] = dt * (fx[k] * vx + fy[k] * vy);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        u[1] += dt * fx[k];
+        u[2] += dt * fy[k];
+        u[3] += work[k];
+        if (r2[k] < near2[k]) {
+            double r_sink = m[k].sink_radius;
+            double dr = sqrt(r2[k]);
+            if (dr < 4.0 * r_sink) {
+                double q = dr / r_sink;
+                double q2 = q * q;
+                double rate = cold[k].sink_rate * exp_cold(-(q2 * q2));
+                if (rate != 0.0) {
+                    double mdot = -(sigma * rate);
+                    u[0] += dt * mdot;
+                    if (m[k].sink_model == 1) {
+                        u[1] += dt * mdot * vx;
+                        u[2] += dt * mdot * vy;
+                        u[3] += dt * (mdot * eps + 0.5 * mdot * (vx * vx + vy * vy));
+                    } else if (m[k].sink_model == 2) {
+                        double rinv = 1.0 / (dr + 1e-12);
+                        double rhx = ddx[k] * rinv, rhy = ddy[k] * rinv;
+                        const double mvx = cold[k].vx, mvy = cold[k].vy;
+                        double dv = (vx - mvx) * rhx + (vy - mvy) * rhy;
+                        double vxs = dv * rhx + mvx;
+                        double vys = dv * rhy + mvy;
+                        u[1] += dt * mdot * vxs;
+                        u[2] += dt * mdot * vys;
+                        u[3] += dt * (mdot * eps + 0.5 * mdot * (vxs * vxs + vys * vys));
+                    }
+                }
+            }
+        }
+    }
+}
+
 // exact wavespeed of one zone, out of line (see iso_exact_speed in sf_iso.hpp)
 __device__ __attribute__((noinline)) double gam_exact_speed(double vx, double vy, double pres, double rho, double gamma)
 {
@@ -628,8 +686,14 @@ __global__ __launch_bounds__(256, SFHIP_GAM_WAVES) void gam_stage_kernel(
                 if (!FULL && !P.constant_softening && hvar) hcc = qha * gam_inv_omega_fast<FULL>(P.m, ea[2], ea[3], oyc0, oyc1);
 #if !defined(SFHIP_DIAG_NO_SOURCES)  // diagnosis builds only (WRONG results): a kernel that fits three waves per SIMD
                 gam_buffer_fast<FULL>(P, xc, yc, yc2, u);
+#if !defined(SFHIP_DIAG_GAM_MASSES_APART)
+                if (FULL) gam_two_masses_fast(P.m, P.sink_near2, Pk->m, ea[2], ea[3], dyc0, dyc1, P.dt, pa, eps, u);
+                else
+#endif
+                {
                 gam_mass_source_fast<FULL>(P.m[0], P.sink_near2[0], &Pk->m[0], ea[2], dyc0, P.dt, pa, eps, hcc, u, FULL ? 1 : P.constant_softening);
                 gam_mass_source_fast<FULL>(P.m[1], P.sink_near2[1], &Pk->m[1], ea[3], dyc1, P.dt, pa, eps, hcc, u, FULL ? 1 : P.constant_softening);
+                }
                 gam_cooling_fast<FULL>(P, pa, eps, rinva, u);
 #endif
 #pragma unroll
