@@ -530,8 +530,8 @@ def roofline_of(args, run, world):
         algorithmic_bytes_per_launch=round(alg_bytes / launches),
         binding={"iso": "balanced between the fp64 instruction stream (0.41 ms per RK2 pair alone) and the memory traffic "
                         "(0.45 ms alone, at 0.85-0.9 of the copy ceiling); together 0.50: DESIGN.md sections 3.1 and 5",
-                 "gam": "fp64 VALU issue at two waves per SIMD (instruction stream alone 0.82 of 0.96 ms, memory traffic "
-                        "alone 0.58): see roofline_valu and DESIGN.md section 5"}.get(
+                 "gam": "its fp64 instruction stream at two waves per SIMD (dependent chains, not issue slots alone: "
+                        "see roofline_valu and DESIGN.md sections 3.1 and 5); its memory traffic alone takes 0.58 ms"}.get(
                      args.solver, "fp64 VALU issue, not HBM: see roofline_valu and DESIGN.md"),
         note=f"launch durations: HIP events around every launch of every {run['stride']}. timed step "
              f"({len(log)} launches inside the timed region), minus the median of 40 empty brackets "
