@@ -263,6 +263,69 @@ __device__ __forceinline__ void dg_mass_source(const DgMass &ms, double x, doubl
     }
 }
 
+// Both point masses of a node: the same operations in the same order on du as two calls of dg_mass_source, with the
+// two gravity terms (a square root, a division and a square root again each) formed side by side ahead of the sink
+// tests, which are divergent and end a scheduling region each.
+__device__ __forceinline__ void dg_two_mass_sources(const DgMass (&ms)[2], double x, double y, double dt,
+                                                    const double (&prim)[3], double (&du)[3])
+{
+    const double sigma = prim[0];
+    double ddx[2], ddy[2], dr[2], fx[2], fy[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        ddx[k] = x - ms[k].x;
+        ddy[k] = y - ms[k].y;
+        double r2 = ddx[k] * ddx[k] + ddy[k] * ddy[k];
+        dr[k] = exact_sqrt0(r2);
+        double rs2 = r2 + ms[k].rsoft * ms[k].rsoft;
+        double fnum = sigma * ms[k].mass * exact_quot(1.0, rs2 * exact_sqrt0(rs2));
+        fx[k] = -fnum * ddx[k];
+        fy[k] = -fnum * ddy[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        double rate = 0.0;
+        if (dr[k] < 4.0 * ms[k].sink_radius) {
+            double s = dr[k] / ms[k].sink_radius;
+            double s2 = s * s;
+            rate = ms[k].sink_rate * exp(-(s2 * s2));
+        }
+        double mdot = sigma * rate * -1.0;
+        du[0] += 0.0;
+        du[1] += fx[k] * dt;
+        du[2] += fy[k] * dt;
+        switch (ms[k].sink_model) {
+        case 1:
+            du[0] += dt * mdot;
+            du[1] += dt * mdot * prim[1];
+            du[2] += dt * mdot * prim[2];
+            break;
+        case 2: {
+            const DgRcp rdr = dg_rcp(dr[k] + 1e-12);
+            double rhx = dg_div(ddx[k], rdr);
+            double rhy = dg_div(ddy[k], rdr);
+            double dv = (prim[1] - ms[k].vx) * rhx + (prim[2] - ms[k].vy) * rhy;
+            double vxs = dv * rhx + ms[k].vx;
+            double vys = dv * rhy + ms[k].vy;
+            du[0] += dt * mdot;
+            du[1] += dt * mdot * vxs;
+            du[2] += dt * mdot * vys;
+            break;
+        }
+        case 3:
+            du[0] += dt * mdot;
+            du[1] += 0.0;
+            du[2] += 0.0;
+            break;
+        default:
+            du[0] += 0.0;
+            du[1] += 0.0;
+            du[2] += 0.0;
+            break;
+        }
+    }
+}
+
 // buffer_source_term, :190-223
 __device__ __forceinline__ void dg_buffer_source(const DgParams &P, double x, double y, double dt, const double (&u)[3],
                                                  double (&du)[3])
@@ -658,9 +721,13 @@ __global__ __launch_bounds__(64, 2) void dg_advance_kernel(DgParams P, const dou
                     }
                 }
                 double du[3] = {0.0, 0.0, 0.0};
-                dg_buffer_source(P, x, y, dt, u, du);
+                dg_buffer_source(Pv, x, y, dt, u, du);
+#if defined(SFHIP_DIAG_DG_MASSES_APART)  // diagnosis builds only: the form before the gravity terms were formed side by side
                 dg_mass_source(Pv.m[0], x, y, dt, p, du);
                 dg_mass_source(Pv.m[1], x, y, dt, p, du);
+#else
+                dg_two_mass_sources(Pv.m, x, y, dt, p, du);
+#endif
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
