@@ -982,25 +982,35 @@ __device__ __forceinline__ double dg_minmod_truncated(double w1, double w0l, dou
     return (double)(int)pick;
 }
 
-// One wave per 64 consecutive zones of a row.  The zones' 27 doubles are contiguous in memory, so the
-// wave moves its 13.8 KB segment (plus the two neighbouring zones in j) through LDS with unit-stride
-// loads and stores; a lane then works on "its" zone in LDS (stride 27 doubles = 54 banks: conflict-free
-// for 64-bit accesses) and only the five doubles it needs of the two neighbours in i come from global
-// memory with the zone stride.  (Lane-per-zone global accesses reached 3.1 TB/s; this kernel only copies.)
-__global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const double *__restrict__ weights1,
-                                                      double *__restrict__ weights2, int clamp_lo, int clamp_hi,
-                                                      int clamp_j, int i_begin)
+// One wave per 64 consecutive zones of a row, DG_LIMIT_ROWS consecutive rows per workgroup.  The zones' 27 doubles are
+// contiguous in memory, so a wave moves its 13.8 KB segment (plus the two neighbouring zones in j) through LDS with
+// unit-stride loads and stores; a lane then works on "its" zone in LDS (stride 27 doubles = 54 banks: conflict-free
+// for 64-bit accesses).  The five doubles it needs of its two neighbours in i come from the tiles of the waves above
+// and below it in the workgroup; only the workgroup's first and last row read them from global memory with the zone
+// stride (one request per lane and double: with every row doing that -- 10 strided requests per lane beside 55
+// unit-stride sweeps per wave -- the kernel took 0.41 ms at 2048^2, without them 0.31).
+// grid: (ceil(nj / 64), ceil((i_end - i_begin) / DG_LIMIT_ROWS)), block (64, DG_LIMIT_ROWS)
+#if !defined(SFHIP_DG_LIMIT_ROWS)
+#define SFHIP_DG_LIMIT_ROWS 4
+#endif
+constexpr int DG_LIMIT_ROWS = SFHIP_DG_LIMIT_ROWS;
+
+__global__ __launch_bounds__(64 * DG_LIMIT_ROWS) void dg_limit_kernel(int ni, int nj, const double *__restrict__ weights1,
+                                                                      double *__restrict__ weights2, int clamp_lo, int clamp_hi,
+                                                                      int clamp_j, int i_begin, int i_end)
 {
     constexpr int SWEEPS = (66 * DG_NW + 63) / 64; // 28 unit-stride sweeps of the wave cover 66 zones
-    __shared__ double tile[SWEEPS * 64];
-    const int t = threadIdx.x;
+    __shared__ double tiles[DG_LIMIT_ROWS][SWEEPS * 64];
+    const int t = threadIdx.x, w = threadIdx.y;
+    double *tile = tiles[w];
     const int j0 = blockIdx.x * 64;
-    const int i = i_begin + blockIdx.y;
+    const int i = i_begin + blockIdx.y * DG_LIMIT_ROWS + w;
+    const bool row_ok = i < i_end; // (a workgroup's last waves may stand beyond the range: they only keep the barriers)
     const int nvalid = nj - j0 < 64 ? nj - j0 : 64;
     const long sj = DG_NW, si = (long)DG_NW * (nj + 2);
-    const double *row = weights1 + (i + 1) * si + (long)j0 * sj; // zone j0 - 1 (a guard zone when j0 == 0)
     const int nload = (nvalid + 2) * DG_NW;
-    {
+    if (row_ok) {
+        const double *row = weights1 + (i + 1) * si + (long)j0 * sj; // zone j0 - 1 (a guard zone when j0 == 0)
         // all loads are issued before the first wait: addresses past the segment are clamped (the
         // value lands in an unused part of the tile) instead of branching around the load
         double staged[SWEEPS];
@@ -1016,7 +1026,7 @@ __global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const doub
     __syncthreads();
 
     const int j = j0 + t;
-    const bool active = t < nvalid;
+    const bool active = row_ok && t < nvalid;
     double wx[3] = {0.0, 0.0, 0.0}, wy[3] = {0.0, 0.0, 0.0};
     bool change[3] = {false, false, false};
     if (active) {
@@ -1024,12 +1034,17 @@ __global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const doub
         const double *lj = (clamp_j && j == 0) ? cc : cc - DG_NW;
         const double *rj = (clamp_j && j == nj - 1) ? cc : cc + DG_NW;
         const double *gcc = weights1 + (i + 1) * si + (j + 1) * sj;
+        // the same zone one row down / up: in a neighbouring wave's tile (still as loaded: nobody has limited yet),
+        // else in global memory
+        const bool lo_tile = w > 0, hi_tile = w + 1 < DG_LIMIT_ROWS && i + 1 < i_end;
+        const double *lo_cc = tiles[lo_tile ? w - 1 : w] + (t + 1) * DG_NW;
+        const double *hi_cc = tiles[hi_tile ? w + 1 : w] + (t + 1) * DG_NW;
         double li[5], ri[5]; // slots [0][0][0], [0][1][0], [0][2][0], [1][0][0], [2][0][0]
         const int need[5] = {0, 3, 6, 9, 18};
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            li[k] = (clamp_lo && i == 0) ? cc[need[k]] : gcc[need[k] - si];
-            ri[k] = (clamp_hi && i == ni - 1) ? cc[need[k]] : gcc[need[k] + si];
+            li[k] = (clamp_lo && i == 0) ? cc[need[k]] : lo_tile ? lo_cc[need[k]] : gcc[need[k] - si];
+            ri[k] = (clamp_hi && i == ni - 1) ? cc[need[k]] : hi_tile ? hi_cc[need[k]] : gcc[need[k] + si];
         }
         const double s3 = 1.7320508075688772, s5 = 2.23606797749979; // sqrt(3.0), sqrt(5.0) correctly rounded
         const double c00 = cc[0];
@@ -1049,7 +1064,7 @@ __global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const doub
             }
         }
     }
-    __syncthreads(); // every lane has read its neighbours' slopes before anyone overwrites them
+    __syncthreads(); // every lane of every wave has read its neighbours' weights before anyone overwrites them
     if (active) {
         double *cc = tile + (t + 1) * DG_NW;
 #pragma unroll
@@ -1064,12 +1079,14 @@ __global__ __launch_bounds__(64) void dg_limit_kernel(int ni, int nj, const doub
         }
     }
     __syncthreads();
-    double *orow = weights2 + (i + 1) * si + (long)(j0 + 1) * sj;
-    const int nstore = nvalid * DG_NW;
+    if (row_ok) {
+        double *orow = weights2 + (i + 1) * si + (long)(j0 + 1) * sj;
+        const int nstore = nvalid * DG_NW;
 #pragma unroll
-    for (int r = 0; r < DG_NW; ++r) {
-        const int k = t + 64 * r;
-        if (k < nstore) orow[k] = tile[DG_NW + k];
+        for (int r = 0; r < DG_NW; ++r) {
+            const int k = t + 64 * r;
+            if (k < nstore) orow[k] = tile[DG_NW + k];
+        }
     }
 }
 

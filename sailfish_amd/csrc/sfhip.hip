@@ -1932,9 +1932,9 @@ int dg_limit_impl(const char *who, int ni, int nj, double *weights1, double *wei
     if (ni < 1 || nj < 1 || !weights1 || !weights2 || weights1 == weights2) return fail(-1, who);
     if (i_begin < 0 || i_end > ni || i_begin > i_end) return fail(-1, "cbdisodg_2d: bad row range");
     if (i_end == i_begin) return 0;
-    dim3 block(64), grid((nj + 63) / 64, i_end - i_begin);
+    dim3 block(64, sf::DG_LIMIT_ROWS), grid((nj + 63) / 64, (i_end - i_begin + sf::DG_LIMIT_ROWS - 1) / sf::DG_LIMIT_ROWS);
     hipLaunchKernelGGL(sf::dg_limit_kernel, grid, block, 0, t_stream, ni, nj, weights1, weights2, clamp_lower_i,
-                       clamp_upper_i, clamp_j, i_begin);
+                       clamp_upper_i, clamp_j, i_begin, i_end);
     return check_launch(who);
 }
 
