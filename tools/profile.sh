@@ -8,6 +8,7 @@ set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
+rm -rf "$out"   # (a tag used twice would mix the two runs' counter files)
 mkdir -p "$out"
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic-pass "$@" > "$out/stats.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$out/sq" -- python3 bench.py --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline --no-events "$@" > "$out/sq.log" 2>&1 || exit 1
