@@ -18,11 +18,22 @@ import collections, csv, glob, json, os, shutil, sys
 tag, name, key = sys.argv[1:4]
 root = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+
+
+def newest(pattern):
+    """gpurun MERGES a call's output into the local directory: a tag used twice holds both runs' files (named by
+    process id), so only the most recent file of each pass directory is read."""
+    by_dir = collections.defaultdict(list)
+    for path in glob.glob(pattern, recursive=True):
+        by_dir[os.path.dirname(path)].append(path)
+    return [max(paths, key=os.path.getmtime) for paths in by_dir.values()]
+
+
+stats = newest(os.path.join(root, "stats", "**", "*kernel_stats.csv"))[0]
 shutil.copy(stats, f"profiles/{name}_kernel_stats.csv")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 clocks = collections.defaultdict(list)  # GHz under each launch: GRBM_GUI_ACTIVE counts every XCD's cycles
-for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+for path in newest(os.path.join(root, "**", "*counter_collection.csv")):
     with open(path) as f:
         for row in csv.DictReader(f):
             kname = row["Kernel_Name"].split("(")[0]
