@@ -63,7 +63,8 @@ int env_int(const char *name, int fallback)
 }
 
 // Split `nrows` rows into chunks, one wave per (chunk, strip).
-// Large patches: about 8192 waves (8 workgroups of 4 waves per CU) and at least 32 rows per chunk, so that the
+// Large patches: about 8192 waves (8 workgroups of 4 waves per CU; cbdgam and srhd, at two waves per SIMD: 9216, i.e.
+// 32-row chunks at 4096^2, 1 % faster there and a wash for cbdiso) and at least 32 rows per chunk, so that the
 // 4-row pipeline warm-up stays small.  On the device the stage time is flat (+-2 %) between 28 and 47 rows per
 // chunk at 4096^2, as for the 1448 x 11584 patch of an 8-rank run (tools/sweep_chunks.sh).
 // Patches that cannot reach that many waves with 32-row chunks are latency-bound, and what a launch takes is
@@ -73,11 +74,11 @@ int env_int(const char *name, int fallback)
 // reproduces the measured optima of the sustained RK2 pair (tools/kbench.py): 3 rows at 512^2 (0.024 ms against
 // 0.038 ms with round 1's 8-row minimum), 10 at 1024^2 (0.050 against 0.060), ~20 at 2048^2, and the flat 6..20
 // of the 512 x 4096 slab of an 8-rank strong-scaling run.
-void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks)
+void plan_rows(int nrows, int nstrips, int *rows_per_chunk, int *nchunks, int default_target_waves = 8192)
 {
     int rpc = env_int("SFHIP_ROWS_PER_CHUNK", 0);
     if (rpc <= 0) {
-        const int target_waves = env_int("SFHIP_TARGET_WAVES", 8192);
+        const int target_waves = env_int("SFHIP_TARGET_WAVES", default_target_waves);
         const int max_nc = (nrows + 31) / 32;
         if ((long)max_nc * nstrips >= target_waves) {
             int nc = (target_waves + nstrips - 1) / nstrips;
@@ -207,7 +208,7 @@ int launch_gam_stage(sf::GamParams &P, const double *prd, const double *unsrc, d
     }
     const int nstrips = (P.nj + sf::STRIP - 1) / sf::STRIP;
     int nchunks;
-    plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks);
+    plan_rows(nrows, nstrips, &P.rows_per_chunk, &nchunks, 9216);
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
@@ -1760,7 +1761,7 @@ static int srhd_advance_impl(int ni, int nj, double *face_positions, double *con
     }
     const int nstrips = (nj + sf::STRIP - 1) / sf::STRIP;
     int rows_per_chunk, nchunks;
-    plan_rows(ni, nstrips, &rows_per_chunk, &nchunks);
+    plan_rows(ni, nstrips, &rows_per_chunk, &nchunks, 9216);
     const long waves = (long)nstrips * nchunks;
     const int wpb = waves_per_block();
     dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
