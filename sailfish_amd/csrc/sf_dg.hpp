@@ -270,25 +270,31 @@ __device__ __forceinline__ void dg_two_mass_sources(const DgMass (&ms)[2], doubl
                                                     const double (&prim)[3], double (&du)[3])
 {
     const double sigma = prim[0];
-    double ddx[2], ddy[2], dr[2], fx[2], fy[2];
+    double ddx[2], ddy[2], r2[2], fx[2], fy[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         ddx[k] = x - ms[k].x;
         ddy[k] = y - ms[k].y;
-        double r2 = ddx[k] * ddx[k] + ddy[k] * ddy[k];
-        dr[k] = exact_sqrt0(r2);
-        double rs2 = r2 + ms[k].rsoft * ms[k].rsoft;
+        r2[k] = ddx[k] * ddx[k] + ddy[k] * ddy[k];
+        double rs2 = r2[k] + ms[k].rsoft * ms[k].rsoft;
         double fnum = sigma * ms[k].mass * exact_quot(1.0, rs2 * exact_sqrt0(rs2));
         fx[k] = -fnum * ddx[k];
         fy[k] = -fnum * ddy[k];
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        double rate = 0.0;
-        if (dr[k] < 4.0 * ms[k].sink_radius) {
-            double s = dr[k] / ms[k].sink_radius;
-            double s2 = s * s;
-            rate = ms[k].sink_rate * exp(-(s2 * s2));
+        // The distance itself is needed inside the sink (dr < 4 r_sink) and by sink model 2 only: its square root is
+        // taken there, behind a test on the squared distance that lets through a little more than the sink (the
+        // exact test decides inside), instead of at every node of every zone.
+        const double rs4 = 4.0 * ms[k].sink_radius;
+        double rate = 0.0, dr_k = 0.0;
+        if (ms[k].sink_model == 2 || r2[k] < rs4 * rs4 * 1.000001) {
+            dr_k = exact_sqrt0(r2[k]);
+            if (dr_k < rs4) {
+                double s = dr_k / ms[k].sink_radius;
+                double s2 = s * s;
+                rate = ms[k].sink_rate * exp(-(s2 * s2));
+            }
         }
         double mdot = sigma * rate * -1.0;
         du[0] += 0.0;
@@ -301,7 +307,7 @@ __device__ __forceinline__ void dg_two_mass_sources(const DgMass (&ms)[2], doubl
             du[2] += dt * mdot * prim[2];
             break;
         case 2: {
-            const DgRcp rdr = dg_rcp(dr[k] + 1e-12);
+            const DgRcp rdr = dg_rcp(dr_k + 1e-12);
             double rhx = dg_div(ddx[k], rdr);
             double rhy = dg_div(ddy[k], rdr);
             double dv = (prim[1] - ms[k].vx) * rhx + (prim[2] - ms[k].vy) * rhy;
